@@ -1,0 +1,92 @@
+"""ctypes binding of libdvf_hip.so (C ABI declared in include/dvf_hip.h).
+
+The library is the product: there is no CPU or stock-torch fallback.  If the shared object is
+missing or a call returns an error code, this module raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdvf_hip.so")
+_lib = None
+
+c_fp = ctypes.c_void_p          # device pointer to float
+c_i = ctypes.c_int
+c_u32 = ctypes.c_uint32
+c_f = ctypes.c_float
+c_i64 = ctypes.c_int64
+c_pp = ctypes.POINTER(ctypes.c_void_p)   # host array of device pointers
+
+ROT_QUAT, PAD_BORDER, ALIGN_CORNERS = 1, 2, 4
+ACT_NONE, ACT_RELU, ACT_SIGMOID_AFFINE = 0, 1, 2
+MAX_VIEWS, MAX_SEGS = 4, 3
+
+# name -> (restype, argtypes); kept in one table so tests can check every declared symbol is exported
+SIGNATURES = {
+    "dvf_version": (c_i, []),
+    "dvf_error_string": (ctypes.c_char_p, [c_i]),
+    "dvf_inverse_warp_fwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_u32, c_fp]),
+    "dvf_inverse_warp_bwd": (c_i, [c_fp] * 10 + [c_i] * 4 + [c_u32, c_fp]),
+    "dvf_pose_ws_floats": (c_i64, [c_i, c_i]),
+    "dvf_photo_loss_fwd": (c_i, [c_fp, c_pp, c_i] + [c_fp] * 8 + [c_i] * 4 + [c_u32, c_fp]),
+    "dvf_photo_partials_floats": (c_i64, [c_i] * 4),
+    "dvf_photo_loss_bwd": (c_i, [c_fp, c_pp, c_i] + [c_fp] * 9 + [c_pp, c_fp, c_fp] + [c_i] * 4 + [c_u32, c_fp]),
+    "dvf_smooth_loss_fwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_f, c_i, c_fp]),
+    "dvf_smooth_partials_floats": (c_i64, [c_i] * 3),
+    "dvf_smooth_loss_bwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_f, c_fp]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `make -C depth-vo-feat_amd/csrc` "
+                "(or __graft_entry__.build()).  There is no fallback path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)           # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {lib().dvf_error_string(rc).decode()} (code {rc})")
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(t, name="tensor"):
+    """Validate a tensor for the C ABI (cuda, fp32, contiguous) and return its device pointer."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the HIP path needs a CUDA/HIP tensor, got {t.device}; there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors, name="tensors"):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else dev(t, f"{name}[{i}]").value
+    return arr
+
+
+def geom_flags(rotation_mode="euler", padding_mode="zeros", align_corners=False):
+    if rotation_mode not in ("euler", "quat"):
+        raise ValueError(f"rotation_mode must be 'euler' or 'quat', got {rotation_mode!r}")
+    if padding_mode not in ("zeros", "border"):
+        raise ValueError(f"padding_mode must be 'zeros' or 'border', got {padding_mode!r}")
+    return ((ROT_QUAT if rotation_mode == "quat" else 0) | (PAD_BORDER if padding_mode == "border" else 0) |
+            (ALIGN_CORNERS if align_corners else 0))

@@ -1,0 +1,127 @@
+"""torch.autograd.Function wrappers over the C ABI: geometry + losses.
+
+Each forward/backward is one (or two) kernel launches on torch's current stream; nothing here
+synchronises with the host, so a whole training step can be captured in a HIP graph.
+"""
+import torch
+
+from . import lib as L
+
+
+def _f32c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+class InverseWarpFn(torch.autograd.Function):
+    """inverse_warp.inverse_warp (reference pytorch_version/inverse_warp.py:160-193)."""
+
+    @staticmethod
+    def forward(ctx, img, depth, pose, K, Kinv, flags):
+        img, depth, pose, K, Kinv = map(_f32c, (img, depth, pose, K, Kinv))
+        B, C, H, W = img.shape
+        out = torch.empty_like(img)
+        L.check(L.lib().dvf_inverse_warp_fwd(L.dev(img, "img"), L.dev(depth, "depth"), L.dev(pose, "pose"),
+                                             L.dev(K, "intrinsics"), L.dev(Kinv, "intrinsics_inv"), L.dev(out),
+                                             B, C, H, W, flags, L.stream()), "dvf_inverse_warp_fwd")
+        ctx.save_for_backward(img, depth, pose, K, Kinv)
+        ctx.flags = flags
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        img, depth, pose, K, Kinv = ctx.saved_tensors
+        B, C, H, W = img.shape
+        need_img, need_depth, need_pose = ctx.needs_input_grad[:3]
+        g_img = torch.zeros_like(img) if need_img else None
+        g_depth = torch.empty_like(depth) if need_depth else None
+        g_pose = torch.empty_like(pose) if need_pose else None
+        ws = torch.empty(int(L.lib().dvf_pose_ws_floats(1, B)), device=img.device) if need_pose else None
+        L.check(L.lib().dvf_inverse_warp_bwd(L.dev(img), L.dev(depth), L.dev(pose), L.dev(K), L.dev(Kinv),
+                                             L.dev(_f32c(gout), "grad_out"), L.dev(g_img), L.dev(g_depth),
+                                             L.dev(g_pose), L.dev(ws), B, C, H, W, ctx.flags, L.stream()),
+                "dvf_inverse_warp_bwd")
+        return g_img, g_depth, g_pose, None, None, None
+
+
+class PhotoLossFn(torch.autograd.Function):
+    """Fused warp + exact-zero mask + (explainability mask) + L1 mean for all views of one scale.
+
+    Inputs: tgt [B,C,H,W], depth [B,H,W], pose [V,B,6], K, Kinv [B,3,3], mask [B,V,H,W] or None,
+    flags, then the V source tensors.  Output: 0-dim loss (sum over views)."""
+
+    @staticmethod
+    def forward(ctx, tgt, depth, pose, K, Kinv, mask, flags, *srcs):
+        tgt, depth, pose, K, Kinv = map(_f32c, (tgt, depth, pose, K, Kinv))
+        srcs = [_f32c(s) for s in srcs]
+        mask = _f32c(mask) if mask is not None else None
+        B, C, H, W = tgt.shape
+        V = len(srcs)
+        lib = L.lib()
+        out = torch.empty(1 + V, device=tgt.device)
+        partials = torch.empty(int(lib.dvf_photo_partials_floats(B, H, W, V)), device=tgt.device)
+        L.check(lib.dvf_photo_loss_fwd(L.dev(tgt, "tgt"), L.ptr_array(srcs, "srcs"), V, L.dev(depth, "depth"),
+                                       L.dev(pose, "pose"), L.dev(K, "intrinsics"), L.dev(Kinv, "intrinsics_inv"),
+                                       L.dev(mask, "mask"), L.dev(out), L.dev(out[1:]), L.dev(partials),
+                                       B, C, H, W, flags, L.stream()), "dvf_photo_loss_fwd")
+        ctx.save_for_backward(tgt, depth, pose, K, Kinv, mask, *srcs)
+        ctx.flags = flags
+        ctx.view_loss = out[1:]
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        tgt, depth, pose, K, Kinv, mask, *srcs = ctx.saved_tensors
+        B, C, H, W = tgt.shape
+        V = len(srcs)
+        need = ctx.needs_input_grad
+        lib = L.lib()
+        g_tgt = torch.empty_like(tgt) if need[0] else None
+        g_depth = torch.empty_like(depth) if need[1] else None
+        g_pose = torch.empty_like(pose) if need[2] else None
+        g_mask = torch.empty_like(mask) if (mask is not None and need[5]) else None
+        g_srcs = [torch.zeros_like(s) if need[7 + i] else None for i, s in enumerate(srcs)]
+        ws = torch.empty(int(lib.dvf_pose_ws_floats(V, B)), device=tgt.device) if need[2] else None
+        gl = _f32c(gloss).reshape(1)
+        L.check(lib.dvf_photo_loss_bwd(L.dev(tgt), L.ptr_array(srcs), V, L.dev(depth), L.dev(pose), L.dev(K),
+                                       L.dev(Kinv), L.dev(mask), L.dev(gl, "grad_loss"), L.dev(g_depth),
+                                       L.dev(g_pose), L.dev(g_tgt), L.ptr_array(g_srcs), L.dev(g_mask), L.dev(ws),
+                                       B, C, H, W, ctx.flags, L.stream()), "dvf_photo_loss_bwd")
+        return (g_tgt, g_depth, g_pose, None, None, g_mask, None, *g_srcs)
+
+
+class SmoothLossFn(torch.autograd.Function):
+    """smooth_loss over a list of maps (reference loss_functions.py:23-41, loss_functions_sfm.py:59-77):
+    sum_s w_s * (mean|dx2| + mean|dxdy| + mean|dydx| + mean|dy2|), w_{s+1} = w_s / scale_factor."""
+
+    @staticmethod
+    def forward(ctx, scale_factor, *maps):
+        maps = [_f32c(m) for m in maps]
+        lib = L.lib()
+        out = torch.empty(1, device=maps[0].device)
+        weights, w = [], 1.0
+        for i, m in enumerate(maps):
+            B, C, H, W = m.shape
+            partials = torch.empty(int(lib.dvf_smooth_partials_floats(B * C, H, W)), device=m.device)
+            L.check(lib.dvf_smooth_loss_fwd(L.dev(m, "pred_map"), L.dev(out), L.dev(partials), B * C, H, W, w,
+                                            1 if i > 0 else 0, L.stream()), "dvf_smooth_loss_fwd")
+            weights.append(w)
+            w /= scale_factor
+        ctx.save_for_backward(*maps)
+        ctx.weights = weights
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        maps = ctx.saved_tensors
+        gl = _f32c(gloss).reshape(1)
+        grads = []
+        for i, (m, w) in enumerate(zip(maps, ctx.weights)):
+            if not ctx.needs_input_grad[1 + i]:
+                grads.append(None)
+                continue
+            B, C, H, W = m.shape
+            g = torch.empty_like(m)
+            L.check(L.lib().dvf_smooth_loss_bwd(L.dev(m), L.dev(gl, "grad_loss"), L.dev(g), B * C, H, W, w,
+                                                L.stream()), "dvf_smooth_loss_bwd")
+            grads.append(g)
+        return (None, *grads)
