@@ -35,6 +35,42 @@ def rel_err(a, b):
     return float((a - b).abs().max()) / (den if den > 0 else 1.0)
 
 
+def outliers(a, b, tol):
+    """Number of elements whose error exceeds tol * max|b|.  Per-pixel gradients of a bilinear sampler
+    are discontinuous where a source coordinate crosses an integer (the 2x2 tap set changes), so a pixel
+    whose coordinate sits within fp32 rounding of such a crossing may legitimately take the other side;
+    tests on random data bound the NUMBER of such pixels instead of requiring zero."""
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return int(((a - b).abs() > tol * float(b.abs().max())).sum())
+
+
+def safe_pixel_mask(depth, poses, K, Kinv, thr=1e-3, rot="euler", tgt=None, srcs=None):
+    """[B,V,H,W] float mask: 0 where the fp64 source coordinate of (pixel, view) lies within `thr` pixels
+    of a tap-set crossing (integer coordinate) or of the |x_n| = 1 overwrite boundary, 1 elsewhere.  At
+    those pixels the reference's own fp32 result is not determined (its gradient is discontinuous there
+    and fp32 coordinate error is ~2e-5 px); the same holds where |tgt - warped| of a channel is within
+    5e-4 (relative to the value range) of its L1 kink (sign flip; the sampled value carries ~1e-4 of coordinate-error noise).  Large-size parity tests therefore feed this mask as the
+    explainability mask to BOTH the oracle and the HIP path: their contribution is then exactly zero in
+    both.  (Small golden cases are compared unmasked.)"""
+    from oracle import geometry as og
+    b, h, w = depth.shape
+    out = []
+    for vi, pose in enumerate(poses):
+        cam = og.pixel2cam(depth.double(), Kinv.double())
+        proj = K.double() @ og.pose_vec2mat(pose.double(), rot)
+        g = og.cam2pixel(cam, proj[:, :, :3], proj[:, :, -1:], "border")
+        xn, yn = g[..., 0], g[..., 1]
+        ix, iy = ((xn + 1) * w - 1) / 2, ((yn + 1) * h - 1) / 2
+        risky = ((ix - ix.round()).abs() < thr) | ((iy - iy.round()).abs() < thr)
+        risky |= ((xn.abs() - 1).abs() < 4 * thr / w) | ((yn.abs() - 1).abs() < 4 * thr / h)
+        if tgt is not None:
+            warped = og.bilinear_sample(srcs[vi].double(), g)
+            risky |= ((tgt.double() - warped).abs() < 5e-4 * float(tgt.abs().max())).any(1)
+        out.append((~risky).to(torch.float32))
+    return torch.stack(out, dim=1)
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
