@@ -1,0 +1,668 @@
+// fp32 MFMA convolution kernels for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, bit-identical to an fmaf
+// chain, so the 1e-4 parity bound holds without any reduced-precision path).
+//
+// Two kernels cover every convolution-shaped op of DispNetS / PoseExpNet / FeatExtractor:
+//
+//  conv_gather_kernel   out[m][Y][X] = sum_r sum_taps W(m, r, tap) * in[r][iy][ix]      ("gather form")
+//      GEMM view: M = output channels (MFMA rows, 32 per tile), N = 32 output pixels per tile (one pixel per
+//      lane -> coalesced NCHW stores), K = (input channel pair) x taps.  The input patch (+halo) of CK channels
+//      and the matching weight slab are staged in LDS once per chunk and re-used by every tap.
+//      Used as: Conv2d forward (stride 1/2), Conv2d dgrad and ConvTranspose2d forward (one launch per output
+//      parity class, so strided layers waste no MACs on zeros), ConvTranspose2d dgrad.  Virtual concat: up to 3
+//      input segments are walked in place of torch.cat.
+//
+//  conv_wgrad_kernel    G[m][c][tap] += sum_pixels P[m][pix] * Q[c][pix*S + tap - pad]
+//      GEMM view: M = P channels, N = 32 (c, tap) columns per tile, K = pixel pairs.  Conv2d: P = dL/dpre,
+//      Q = input;  ConvTranspose2d: P = input, Q = dL/dpre.  Each block keeps its G tile in MFMA accumulators
+//      across many pixel tiles and adds it to global memory once.
+//
+// Layouts are the reference's (NCHW activations, OIHW / IOHW weights): nothing is repacked between steps.
+#include "dvf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GatherArgs {
+    const float *in[DVF_MAX_SEGS];
+    int segC[DVF_MAX_SEGS];
+    int nseg;
+    const float *w;
+    int w_mode;          // 0: w[((m_base+m)*Rtot + r)*KK + tap]   1: w[(r*Mtot + m_base+m)*KK + tap]
+    int Mtot, Rtot, KK, m_base, M;
+    const float *bias;   // indexed by m (already offset by the caller) or NULL
+    float *out;          // [N, M, OH, OW]
+    int N, IH, IW, OH, OW, OHc, OWc;
+    int OS, py, px;      // output pixel (oy*OS+py, ox*OS+px)
+    int IS, by, bx;      // input  pixel (oy*IS+by+ta, ox*IS+bx+tb)
+    int TA, TB;
+    int act;
+    float alpha, beta;
+    int CK, lck, KS, NCH, atomic_out;
+    int lsw, lsh, TGX, BW, BH, tilesX, tilesY;
+    int PH, PW, PWH, RS, PS, COTP;
+    int tapmap[49];
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float alpha, float beta) {
+    if (act == DVF_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == DVF_ACT_SIGMOID_AFFINE) return alpha * (1.f / (1.f + expf(-v))) + beta;
+    return v;
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *patch = smem;                       // [CK][PH][RS] (IS==2: columns de-interleaved by parity)
+    float *wl = smem + a.CK * a.PS;            // [T][CK][COTP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, kh = lane >> 5;
+    const int n = blockIdx.z / a.KS, ks = blockIdx.z - n * a.KS;
+    const int tX = blockIdx.x % a.tilesX, tY = blockIdx.x / a.tilesX;
+    const int oy0 = tY * a.BH, ox0 = tX * a.BW;
+    const int m0 = blockIdx.y * (32 * MT);
+    const int SW = 1 << a.lsw, SH = 1 << a.lsh;
+    const int pxl = nl & (SW - 1), pyl = nl >> a.lsw;
+    const int T = a.TA * a.TB, CK = a.CK;
+
+    int boff[NT], opy[NT], opx[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int q = wave * NT + i, tx = q % a.TGX, ty = q / a.TGX;
+        opy[i] = ty * SH + pyl;
+        opx[i] = tx * SW + pxl;
+        boff[i] = kh * a.PS + (opy[i] * a.IS) * a.RS + opx[i];
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
+
+    const int iy0 = oy0 * a.IS + a.by, ix0 = ox0 * a.IS + a.bx;
+    const int g_begin = (int)(((int64_t)a.NCH * ks) / a.KS), g_end = (int)(((int64_t)a.NCH * (ks + 1)) / a.KS);
+    // walk the chunks of the (virtually concatenated) input segments
+    int seg = 0, seg_first = 0, r_seg = 0;     // r_seg: index of the segment's first channel in the concat
+    for (int g = g_begin; g < g_end; ++g) {
+        while (true) {
+            const int nchs = (a.segC[seg] + CK - 1) >> a.lck;
+            if (g < seg_first + nchs) break;
+            seg_first += nchs;
+            r_seg += a.segC[seg];
+            ++seg;
+        }
+        const int c0 = (g - seg_first) << a.lck;              // first channel of the chunk inside its segment
+        const int nch = min(CK, a.segC[seg] - c0);            // valid channels in this chunk
+        const float *src = a.in[seg] + ((int64_t)n * a.segC[seg] + c0) * a.IH * a.IW;
+        __syncthreads();                                      // previous chunk fully consumed
+        // ---- stage the input patch
+        {
+            int ci = 0, r = wave;
+            while (r >= a.PH) { r -= a.PH; ++ci; }
+            while (ci < CK) {
+                const int iy = iy0 + r;
+                const bool rowok = (ci < nch) && (iy >= 0) && (iy < a.IH);
+                const float *rp = src + ((int64_t)ci * a.IH + iy) * a.IW;
+                float *dp = patch + ci * a.PS + r * a.RS;
+                for (int c = lane; c < a.PW; c += 64) {
+                    const int ix = ix0 + c;
+                    const float v = (rowok && ix >= 0 && ix < a.IW) ? rp[ix] : 0.f;
+                    const int pos = (a.IS == 2) ? ((c & 1) * a.PWH + (c >> 1)) : c;
+                    dp[pos] = v;
+                }
+                r += 4;
+                while (r >= a.PH) { r -= a.PH; ++ci; }
+            }
+        }
+        // ---- stage the weight slab: wl[(t*CK + r)*COTP + m]
+        {
+            const int r0 = r_seg + c0;                        // reduction index of the chunk's first channel
+            if (a.w_mode == 0) {
+                const int rr = lane & (CK - 1), msub = lane >> a.lck, mstep = 64 >> a.lck;
+                for (int m = msub + mstep * wave; m < 32 * MT; m += mstep * 4) {
+                    const bool ok = (m0 + m < a.M) && (rr < nch);
+                    const float *wp = a.w + ((int64_t)(a.m_base + m0 + m) * a.Rtot + r0 + rr) * a.KK;
+                    for (int t = 0; t < T; ++t)
+                        wl[(t * CK + rr) * a.COTP + m] = ok ? wp[a.tapmap[t]] : 0.f;
+                }
+            } else {
+                for (int mm = lane; mm < 32 * MT; mm += 64) {
+                    for (int rr = wave; rr < CK; rr += 4) {
+                        const bool ok = (m0 + mm < a.M) && (rr < nch);
+                        const float *wp = a.w + ((int64_t)(r0 + rr) * a.Mtot + a.m_base + m0 + mm) * a.KK;
+                        for (int t = 0; t < T; ++t)
+                            wl[(t * CK + rr) * a.COTP + mm] = ok ? wp[a.tapmap[t]] : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over (channel pair, tap)
+        for (int cp = 0; cp < (CK >> 1); ++cp) {
+            for (int ta = 0; ta < a.TA; ++ta) {
+                for (int tb = 0; tb < a.TB; ++tb) {
+                    const int t = ta * a.TB + tb;
+                    const int toff = (a.IS == 2) ? ((tb & 1) * a.PWH + (tb >> 1)) : tb;
+                    const int po = cp * 2 * a.PS + ta * a.RS + toff;
+                    const int wo = (t * CK + cp * 2 + kh) * a.COTP + nl;
+                    float af[MT], bf[NT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) af[m] = wl[wo + m * 32];
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) bf[i] = patch[boff[i] + po];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < NT; ++i)
+                            acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[i], acc[m][i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- epilogue: D[row = channel][col = pixel]; lanes 0-31 / 32-63 hold channel rows +0 / +4
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int oy = oy0 + opy[i], ox = ox0 + opx[i];
+        const int Y = oy * a.OS + a.py, X = ox * a.OS + a.px;
+        const bool pok = (oy < a.OHc) && (ox < a.OWc) && (Y < a.OH) && (X < a.OW);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = m0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (pok && mm < a.M) {
+                    float *op = a.out + (((int64_t)n * a.M + mm) * a.OH + Y) * a.OW + X;
+                    float v = acc[m][i][r];
+                    if (!a.atomic_out) {
+                        if (a.bias) v += a.bias[mm];
+                        *op = apply_act(v, a.act, a.alpha, a.beta);
+                    } else {
+                        atomicAdd(op, v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// y = act(y + bias[c]) in place: finishes a split-K convolution.
+__global__ void bias_act_kernel(float *y, const float *bias, int C, int64_t HW, int64_t total, int act, float alpha,
+                                float beta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HW) % C);
+        float v = y[i];
+        if (bias) v += bias[c];
+        y[i] = apply_act(v, act, alpha, beta);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+struct WgradArgs {
+    const float *P;      // [N, PCtot, GH, GW]; rows m_base .. m_base+M-1 are used
+    const float *Q;      // [N, QCtot, QH, QW]; channels q_base .. q_base+Cq-1 are used
+    float *G;            // G[(m_base_g + m) * g_mstride + (g_cbase + c) * KK + tap]
+    int PCtot, m_base, M, QCtot, q_base, Cq;
+    int64_t g_mstride;
+    int g_mbase, g_cbase, KK, KH, KW;
+    int N, GH, GW, QH, QW, S, pad;
+    int CK, BH, lnp, tilesX, tilesY, PSPLIT;
+    int PHq, PWq, PWH, RS, PS, COTP;
+};
+
+constexpr int WG_BW = 32;
+
+template <int MT, int NTW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *qp = smem;                               // [CK][PHq][RS]
+    float *pl = smem + a.CK * a.PS;                 // [BH*32 pixels][COTP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.x * (32 * MT);
+    const int c0 = blockIdx.y * a.CK;
+    const int nch = min(a.CK, a.Cq - c0);
+    const int T = a.KH * a.KW;
+    const int ncols = nch * T;
+    // this lane's columns: tile u of this wave covers columns (wave*NTW+u)*32 + nl
+    int loff[NTW], gcol[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        const int j = (wave * NTW + u) * 32 + nl;
+        if (j < ncols) {
+            const int cj = j / T, tj = j - cj * T, ta = tj / a.KW, tb = tj - ta * a.KW;
+            const int toff = (a.S == 2) ? ((tb & 1) * a.PWH + (tb >> 1)) : tb;
+            loff[u] = cj * a.PS + ta * a.RS + toff;
+            gcol[u] = (a.g_cbase + c0 + cj) * a.KK + tj;
+        } else {
+            loff[u] = 0;
+            gcol[u] = -1;
+        }
+    }
+    f32x16 acc[MT][NTW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int u = 0; u < NTW; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][u][r] = 0.f;
+
+    const int ntiles = a.N * a.tilesX * a.tilesY;
+    for (int tile = blockIdx.z; tile < ntiles; tile += a.PSPLIT) {
+        const int n = tile / (a.tilesX * a.tilesY), rem = tile - n * (a.tilesX * a.tilesY);
+        const int tY = rem / a.tilesX, tX = rem - tY * a.tilesX;
+        const int gy0 = tY * a.BH, gx0 = tX * WG_BW;
+        __syncthreads();
+        // ---- stage Q patch
+        {
+            const int qy0 = gy0 * a.S - a.pad, qx0 = gx0 * a.S - a.pad;
+            const float *src = a.Q + ((int64_t)n * a.QCtot + a.q_base + c0) * a.QH * a.QW;
+            int ci = 0, r = wave;
+            while (r >= a.PHq) { r -= a.PHq; ++ci; }
+            while (ci < a.CK) {
+                const int iy = qy0 + r;
+                const bool rowok = (ci < nch) && (iy >= 0) && (iy < a.QH);
+                const float *rp = src + ((int64_t)ci * a.QH + iy) * a.QW;
+                float *dp = qp + ci * a.PS + r * a.RS;
+                for (int c = lane; c < a.PWq; c += 64) {
+                    const int ix = qx0 + c;
+                    const float v = (rowok && ix >= 0 && ix < a.QW) ? rp[ix] : 0.f;
+                    const int pos = (a.S == 2) ? ((c & 1) * a.PWH + (c >> 1)) : c;
+                    dp[pos] = v;
+                }
+                r += 4;
+                while (r >= a.PHq) { r -= a.PHq; ++ci; }
+            }
+        }
+        // ---- stage P tile transposed: pl[pixel][m]; half-wave = one row of 32 pixels
+        {
+            const int npairs = a.BH >> 1;          // row pairs per channel
+            const int px = lane & 31, prow = lane >> 5;
+            for (int idx = wave; idx < 32 * MT * npairs; idx += 4) {
+                const int m = idx >> a.lnp, rp = idx - (m << a.lnp);
+                const int py = rp * 2 + prow;
+                const int gy = gy0 + py, gx = gx0 + px;
+                float v = 0.f;
+                if (m0 + m < a.M && gy < a.GH && gx < a.GW)
+                    v = a.P[(((int64_t)n * a.PCtot + a.m_base + m0 + m) * a.GH + gy) * a.GW + gx];
+                pl[(py * WG_BW + px) * a.COTP + m] = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over pixel pairs
+        for (int py = 0; py < a.BH; ++py) {
+            for (int px = 0; px < WG_BW; px += 2) {
+                const int p = py * WG_BW + px + kh;
+                const int qo = (py * a.S) * a.RS + px + kh;       // column part: pixel x (+tap offset in loff)
+                float af[MT], bf[NTW];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[m] = pl[p * a.COTP + m * 32 + nl];
+#pragma unroll
+                for (int u = 0; u < NTW; ++u) bf[u] = qp[loff[u] + qo];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int u = 0; u < NTW; ++u)
+                        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[u], acc[m][u], 0, 0, 0);
+            }
+        }
+    }
+    // ---- add the G tile: row = P channel, col = (c, tap)
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        if (gcol[u] < 0) continue;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = m0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (mm < a.M) atomicAdd(a.G + (int64_t)(a.g_mbase + mm) * a.g_mstride + gcol[u], acc[m][u][r]);
+            }
+    }
+}
+
+// dpre = dY * act'(Y) and dbias[c] += sum dpre  (one pass; dbias zeroed by the caller side of the ABI)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *dy, const float *y, float *dpre, float *dbias, int C,
+                                                      int HW, int act, float alpha, float beta, int chunks) {
+    __shared__ float red[4];
+    const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
+    const int c = plane % C;
+    const int per = (HW + chunks - 1) / chunks;
+    const int beg = chunk * per, end = min(HW, beg + per);
+    const int64_t base = (int64_t)plane * HW;
+    float s = 0.f;
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+        float g = dy[base + i];
+        if (act == DVF_ACT_RELU) {
+            g = (y[base + i] > 0.f) ? g : 0.f;
+        } else if (act == DVF_ACT_SIGMOID_AFFINE) {
+            const float sg = (y[base + i] - beta) / alpha;      // sigmoid value
+            g = g * alpha * sg * (1.f - sg);
+        }
+        if (dpre) dpre[base + i] = g;
+        s += g;
+    }
+    if (dbias) {
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&dbias[c], (red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------- host planning
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+struct TilePlan { int lsw, lsh, TGX, TGY, NT; };
+
+// pick the 32-pixel tile shape and the arrangement of a block's tiles that waste the fewest MFMA columns
+TilePlan plan_tiles(int OHc, int OWc, int NT) {
+    TilePlan best{5, 0, 1, 4 * NT, NT};
+    double best_cost = 1e30;
+    for (int lsw = 5; lsw >= 0; --lsw) {
+        const int lsh = 5 - lsw, SW = 1 << lsw, SH = 1 << lsh;
+        for (int TGX = 1; TGX <= 4 * NT; TGX *= 2) {
+            const int TGY = 4 * NT / TGX, BW = TGX * SW, BH = TGY * SH;
+            if (BW > 64) continue;
+            const double cov = (double)cdiv(OWc, BW) * BW * cdiv(OHc, BH) * BH;
+            // small preference for wide tiles (coalesced stores) and compact patches
+            const double cost = cov * (1.0 + 0.02 * lsh) + 1e-3 * (BW + BH);
+            if (cost < best_cost) { best_cost = cost; best = TilePlan{lsw, lsh, TGX, TGY, NT}; }
+        }
+    }
+    return best;
+}
+
+struct ClassSpec { int OS, py, px, IS, by, bx, TA, TB, OHc, OWc; int tapmap[49]; };
+
+// Fill the tiling fields of `a` for one class; returns the split-K factor (>= 1) or a negative error.
+int plan_gather(GatherArgs &a, const ClassSpec &cs) {
+    a.OS = cs.OS; a.py = cs.py; a.px = cs.px; a.IS = cs.IS; a.by = cs.by; a.bx = cs.bx;
+    a.TA = cs.TA; a.TB = cs.TB; a.OHc = cs.OHc; a.OWc = cs.OWc;
+    const int T = cs.TA * cs.TB;
+    if (T < 1 || T > 49 || cs.OHc <= 0 || cs.OWc <= 0) return DVF_ERR_INVALID_ARG;
+    for (int t = 0; t < T; ++t) a.tapmap[t] = cs.tapmap[t];
+    const int MT = a.M > 32 ? 2 : 1;
+    const int64_t npix = (int64_t)cs.OHc * cs.OWc;
+    const int NT = (npix * a.N >= 4096) ? 2 : 1;
+    const TilePlan tp = plan_tiles(cs.OHc, cs.OWc, NT);
+    a.lsw = tp.lsw; a.lsh = tp.lsh; a.TGX = tp.TGX;
+    a.BW = tp.TGX << tp.lsw; a.BH = tp.TGY << tp.lsh;
+    a.tilesX = cdiv(cs.OWc, a.BW);
+    a.tilesY = cdiv(cs.OHc, a.BH);
+    a.PH = (a.BH - 1) * a.IS + a.TA;
+    a.PW = (a.BW - 1) * a.IS + a.TB;
+    a.PWH = (a.PW + 1) / 2;
+    a.RS = (a.IS == 2) ? 2 * a.PWH : a.PW;
+    a.PS = a.PH * a.RS;
+    a.COTP = 32 * MT + 1;
+    int maxc = 0;
+    for (int s = 0; s < a.nseg; ++s) maxc = a.segC[s] > maxc ? a.segC[s] : maxc;
+    // largest power-of-two chunk whose LDS footprint stays <= 40 KiB (3+ blocks per CU)
+    int CK = 16;
+    while (CK > 2 && ((int64_t)CK * a.PS + (int64_t)T * CK * a.COTP) * 4 > 40 * 1024) CK >>= 1;
+    while (CK > 2 && CK / 2 >= maxc) CK >>= 1;
+    a.CK = CK; a.lck = ilog2(CK);
+    if (((int64_t)CK * a.PS + (int64_t)T * CK * a.COTP) * 4 > 64 * 1024) return DVF_ERR_UNSUPPORTED;
+    a.NCH = 0;
+    for (int s = 0; s < a.nseg; ++s) a.NCH += cdiv(a.segC[s], CK);
+    const int64_t nblk = (int64_t)a.tilesX * a.tilesY * cdiv(a.M, 32 * MT) * a.N;
+    int KS = 1;
+    if (nblk < 512) KS = (int)((768 + nblk - 1) / nblk);
+    if (KS > a.NCH) KS = a.NCH;
+    if (KS < 1) KS = 1;
+    if ((int64_t)a.N * KS > 65535) return DVF_ERR_UNSUPPORTED;
+    a.KS = KS;
+    return KS;
+}
+
+int run_gather(const GatherArgs &a, hipStream_t st) {
+    const int MT = a.M > 32 ? 2 : 1;
+    const int NT = ((a.BW >> a.lsw) * (a.BH >> a.lsh)) / 4;
+    const int T = a.TA * a.TB;
+    const size_t lds = ((size_t)a.CK * a.PS + (size_t)T * a.CK * a.COTP) * 4;
+    const dim3 grid(a.tilesX * a.tilesY, cdiv(a.M, 32 * MT), a.N * a.KS);
+    if (MT == 2 && NT == 2) conv_gather_kernel<2, 2><<<grid, 256, lds, st>>>(a);
+    else if (MT == 2) conv_gather_kernel<2, 1><<<grid, 256, lds, st>>>(a);
+    else if (NT == 2) conv_gather_kernel<1, 2><<<grid, 256, lds, st>>>(a);
+    else conv_gather_kernel<1, 1><<<grid, 256, lds, st>>>(a);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+// Run the classes of one op.  If any class needs split-K every class accumulates with atomics into a zeroed
+// output and bias + activation are applied by one finishing pass; otherwise they are fused in the epilogue.
+int run_classes(const GatherArgs &base, const ClassSpec *cls, int ncls, bool covers_all, hipStream_t st) {
+    GatherArgs planned[4];
+    if (ncls < 1 || ncls > 4) return DVF_ERR_INVALID_ARG;
+    bool split = !covers_all;
+    for (int i = 0; i < ncls; ++i) {
+        planned[i] = base;
+        const int ks = plan_gather(planned[i], cls[i]);
+        if (ks < 0) return ks;
+        if (ks > 1) split = true;
+    }
+    const int64_t HW = (int64_t)base.OH * base.OW, total = (int64_t)base.N * base.M * HW;
+    if (split && hipMemsetAsync(base.out, 0, sizeof(float) * total, st) != hipSuccess) return DVF_ERR_LAUNCH;
+    for (int i = 0; i < ncls; ++i) {
+        planned[i].atomic_out = split ? 1 : 0;
+        const int rc = run_gather(planned[i], st);
+        if (rc) return rc;
+    }
+    if (split && (base.bias || base.act != DVF_ACT_NONE)) {
+        const int64_t nb = (total + 255) / 256;
+        bias_act_kernel<<<(int)(nb > 2048 ? 2048 : nb), 256, 0, st>>>(base.out, base.bias, base.M, HW, total, base.act,
+                                                                     base.alpha, base.beta);
+        DVF_LAUNCH_CHECK();
+    }
+    return DVF_OK;
+}
+
+// Taps of output-parity class `c` for the relation  Y = o*S - pad + a  <=>  o = (Y + pad - a) / S.
+// Taps are listed so that o = (Y - c)/S + base + index.  Returns the tap count.
+int class_taps(int c, int S, int pad, int K, int *taps, int *base) {
+    int amax = -1;
+    for (int a = K - 1; a >= 0; --a)
+        if ((c + pad - a) % S == 0) { amax = a; break; }
+    if (amax < 0) { *base = 0; return 0; }
+    int cnt = 0;
+    for (int a = amax; a >= 0; a -= S) taps[cnt++] = a;
+    *base = (c + pad - amax) / S;     // exact division (possibly negative)
+    return cnt;
+}
+
+// classes of the scatter relation for an output of size OHxOW
+int scatter_classes(int S, int pad, int KH, int KW, int OH, int OW, ClassSpec *cls, bool *covers_all) {
+    int n = 0;
+    *covers_all = true;
+    for (int cy = 0; cy < S; ++cy)
+        for (int cx = 0; cx < S; ++cx) {
+            int ta[7], tb[7], by, bx;
+            const int na = class_taps(cy, S, pad, KH, ta, &by), nb = class_taps(cx, S, pad, KW, tb, &bx);
+            const int OHc = (OH - cy + S - 1) / S, OWc = (OW - cx + S - 1) / S;
+            if (OHc <= 0 || OWc <= 0) continue;
+            if (na == 0 || nb == 0) { *covers_all = false; continue; }
+            ClassSpec &c = cls[n++];
+            c = ClassSpec{S, cy, cx, 1, by, bx, na, nb, OHc, OWc, {0}};
+            for (int i = 0; i < na; ++i)
+                for (int j = 0; j < nb; ++j) c.tapmap[i * nb + j] = ta[i] * KW + tb[j];
+        }
+    return n;
+}
+
+int check_desc(const dvf_conv_desc *d) {
+    if (!d) return DVF_ERR_INVALID_ARG;
+    if (d->N <= 0 || d->C_in <= 0 || d->C_out <= 0 || d->H_in <= 0 || d->W_in <= 0 || d->H_out <= 0 || d->W_out <= 0)
+        return DVF_ERR_INVALID_ARG;
+    if (d->KH < 1 || d->KW < 1 || d->KH > 7 || d->KW > 7 || (d->stride != 1 && d->stride != 2) || d->pad < 0)
+        return DVF_ERR_INVALID_ARG;
+    return DVF_OK;
+}
+
+int check_segs(const dvf_conv_desc *d, const int *seg_channels, int nseg) {
+    if (nseg < 1 || nseg > DVF_MAX_SEGS || !seg_channels) return DVF_ERR_INVALID_ARG;
+    int tot = 0;
+    for (int s = 0; s < nseg; ++s) {
+        if (seg_channels[s] <= 0) return DVF_ERR_INVALID_ARG;
+        tot += seg_channels[s];
+    }
+    return tot == d->C_in ? DVF_OK : DVF_ERR_INVALID_ARG;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvf_conv2d_fwd(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                   const float *w, const float *bias, float *out, void *stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    rc = check_segs(d, seg_channels, nseg);
+    if (rc) return rc;
+    if (!in_segs || !w || !out) return DVF_ERR_INVALID_ARG;
+    GatherArgs a{};
+    for (int s = 0; s < nseg; ++s) {
+        if (!in_segs[s]) return DVF_ERR_INVALID_ARG;
+        a.in[s] = in_segs[s];
+        a.segC[s] = seg_channels[s];
+    }
+    a.nseg = nseg; a.w = w; a.KK = d->KH * d->KW; a.m_base = 0; a.M = d->C_out; a.bias = bias; a.out = out;
+    a.Mtot = d->C_out; a.Rtot = d->C_in;
+    a.N = d->N; a.IH = d->H_in; a.IW = d->W_in; a.OH = d->H_out; a.OW = d->W_out;
+    a.act = d->act; a.alpha = d->alpha; a.beta = d->beta;
+    ClassSpec cls[4];
+    if (!d->transposed) {
+        // out[co][oy][ox] = sum_ci sum_ab W[co][ci][a][b] * in[ci][oy*s - p + a][ox*s - p + b]
+        a.w_mode = 0;
+        cls[0] = ClassSpec{1, 0, 0, d->stride, -d->pad, -d->pad, d->KH, d->KW, d->H_out, d->W_out, {0}};
+        for (int t = 0; t < a.KK; ++t) cls[0].tapmap[t] = t;
+        return run_classes(a, cls, 1, true, dvf_stream(stream));
+    }
+    // out[co][Y][X] = sum_ci sum_ab W[ci][co][a][b] * in[ci][i][j],  Y = i*s - p + a   (one launch per parity)
+    a.w_mode = 1;
+    bool covers;
+    const int ncls = scatter_classes(d->stride, d->pad, d->KH, d->KW, d->H_out, d->W_out, cls, &covers);
+    return run_classes(a, cls, ncls, covers, dvf_stream(stream));
+}
+
+int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *const *din_segs,
+                     const int *seg_channels, int nseg, void *stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    rc = check_segs(d, seg_channels, nseg);
+    if (rc) return rc;
+    if (!dpre || !w || !din_segs) return DVF_ERR_INVALID_ARG;
+    int off = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const int segc = seg_channels[s];
+        if (din_segs[s]) {
+            GatherArgs a{};
+            a.in[0] = dpre; a.segC[0] = d->C_out; a.nseg = 1;
+            a.w = w; a.KK = d->KH * d->KW; a.m_base = off; a.M = segc; a.bias = nullptr; a.out = din_segs[s];
+            a.Mtot = d->C_in; a.Rtot = d->C_out;
+            a.N = d->N; a.IH = d->H_out; a.IW = d->W_out; a.OH = d->H_in; a.OW = d->W_in;
+            a.act = DVF_ACT_NONE;
+            ClassSpec cls[4];
+            if (!d->transposed) {
+                // din[ci][Y][X] = sum_co sum_ab W[co][ci][a][b] * dpre[co][o][..],  Y = o*s - p + a
+                a.w_mode = 1;
+                bool covers;
+                const int ncls = scatter_classes(d->stride, d->pad, d->KH, d->KW, d->H_in, d->W_in, cls, &covers);
+                rc = run_classes(a, cls, ncls, covers, dvf_stream(stream));
+            } else {
+                // din[ci][i][j] = sum_co sum_ab W[ci][co][a][b] * dpre[co][i*s - p + a][j*s - p + b]
+                a.w_mode = 0;
+                cls[0] = ClassSpec{1, 0, 0, d->stride, -d->pad, -d->pad, d->KH, d->KW, d->H_in, d->W_in, {0}};
+                for (int t = 0; t < a.KK; ++t) cls[0].tapmap[t] = t;
+                rc = run_classes(a, cls, 1, true, dvf_stream(stream));
+            }
+            if (rc) return rc;
+        }
+        off += segc;
+    }
+    return DVF_OK;
+}
+
+int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                     const float *dpre, float *dw, int accumulate, void *stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    rc = check_segs(d, seg_channels, nseg);
+    if (rc) return rc;
+    if (!in_segs || !dpre || !dw) return DVF_ERR_INVALID_ARG;
+    hipStream_t st = dvf_stream(stream);
+    const int KK = d->KH * d->KW;
+    if (!accumulate &&
+        hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->C_in * d->C_out * KK, st) != hipSuccess)
+        return DVF_ERR_LAUNCH;
+    int off = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const int segc = seg_channels[s];
+        if (!in_segs[s]) return DVF_ERR_INVALID_ARG;
+        WgradArgs a{};
+        a.KK = KK; a.KH = d->KH; a.KW = d->KW; a.N = d->N; a.S = d->stride; a.pad = d->pad; a.G = dw;
+        if (!d->transposed) {
+            // dW[co][ci][a][b] = sum dpre[co][o] * in[ci][o*s - p + (a,b)]
+            a.P = dpre; a.PCtot = d->C_out; a.m_base = 0; a.M = d->C_out; a.GH = d->H_out; a.GW = d->W_out;
+            a.Q = in_segs[s]; a.QCtot = segc; a.q_base = 0; a.Cq = segc; a.QH = d->H_in; a.QW = d->W_in;
+            a.g_mstride = (int64_t)d->C_in * KK; a.g_mbase = 0; a.g_cbase = off;
+        } else {
+            // dW[ci][co][a][b] = sum in[ci][i] * dpre[co][i*s - p + (a,b)]
+            a.P = in_segs[s]; a.PCtot = segc; a.m_base = 0; a.M = segc; a.GH = d->H_in; a.GW = d->W_in;
+            a.Q = dpre; a.QCtot = d->C_out; a.q_base = 0; a.Cq = d->C_out; a.QH = d->H_out; a.QW = d->W_out;
+            a.g_mstride = (int64_t)d->C_out * KK; a.g_mbase = off; a.g_cbase = 0;
+        }
+        const int MT = a.M > 32 ? 2 : 1;
+        const int NTW = KK >= 25 ? 2 : 1;
+        int CK = (128 * NTW) / KK;
+        if (CK < 1) CK = 1;
+        if (CK > a.Cq) CK = a.Cq;
+        a.CK = CK;
+        a.BH = a.GH <= 2 ? 2 : 4;
+        a.lnp = ilog2(a.BH >> 1);
+        a.tilesX = cdiv(a.GW, WG_BW);
+        a.tilesY = cdiv(a.GH, a.BH);
+        a.PHq = (a.BH - 1) * a.S + a.KH;
+        a.PWq = (WG_BW - 1) * a.S + a.KW;
+        a.PWH = (a.PWq + 1) / 2;
+        a.RS = (a.S == 2) ? 2 * a.PWH : a.PWq;
+        a.PS = a.PHq * a.RS;
+        a.COTP = 32 * MT + 1;
+        // keep the block's LDS (Q patch + transposed P tile) under 48 KiB: 3 blocks per CU
+        while (CK > 1 && ((size_t)CK * a.PS + (size_t)a.BH * WG_BW * a.COTP) * 4 > 48 * 1024) --CK;
+        a.CK = CK;
+        const int mtiles = cdiv(a.M, 32 * MT), cchunks = cdiv(a.Cq, CK);
+        const int ntiles = a.N * a.tilesX * a.tilesY;
+        int psplit = 1024 / (mtiles * cchunks);
+        if (psplit < 1) psplit = 1;
+        if (psplit > ntiles) psplit = ntiles;
+        if (psplit > 65535 || cchunks > 65535) return DVF_ERR_UNSUPPORTED;
+        a.PSPLIT = psplit;
+        const size_t lds = ((size_t)CK * a.PS + (size_t)a.BH * WG_BW * a.COTP) * 4;
+        if (lds > 64 * 1024) return DVF_ERR_UNSUPPORTED;
+        const dim3 grid(mtiles, cchunks, psplit);
+        if (MT == 2 && NTW == 2) conv_wgrad_kernel<2, 2><<<grid, 256, lds, st>>>(a);
+        else if (MT == 2) conv_wgrad_kernel<2, 1><<<grid, 256, lds, st>>>(a);
+        else if (NTW == 2) conv_wgrad_kernel<1, 2><<<grid, 256, lds, st>>>(a);
+        else conv_wgrad_kernel<1, 1><<<grid, 256, lds, st>>>(a);
+        DVF_LAUNCH_CHECK();
+        off += segc;
+    }
+    return DVF_OK;
+}
+
+int dvf_act_bwd(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act, float alpha,
+                float beta, void *stream) {
+    if (!dy || (act != DVF_ACT_NONE && !y) || N <= 0 || C <= 0 || HW <= 0) return DVF_ERR_INVALID_ARG;
+    if (!dpre && !dbias) return DVF_OK;
+    hipStream_t st = dvf_stream(stream);
+    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) return DVF_ERR_LAUNCH;
+    int chunks = (HW + 4095) / 4096;
+    const int64_t planes = (int64_t)N * C;
+    while (chunks > 1 && planes * chunks > 16384) chunks >>= 1;
+    act_bwd_kernel<<<(unsigned)(planes * chunks), 256, 0, st>>>(dy, y, dpre, dbias, C, HW, act, alpha, beta, chunks);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+}  // extern "C"

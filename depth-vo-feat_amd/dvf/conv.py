@@ -1,0 +1,228 @@
+"""Convolution / transposed convolution with fused bias + activation as autograd Functions over the
+fp32-MFMA kernels of libdvf_hip.so, the small memory-bound ops around them, and the nn.Module shells whose
+parameter names and shapes equal the reference's (so ``state_dict`` files interchange)."""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+
+
+def _c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def conv_out_size(h, k, stride, pad, opad, transposed):
+    return (h - 1) * stride - 2 * pad + k + opad if transposed else (h + 2 * pad - k) // stride + 1
+
+
+class ConvFn(torch.autograd.Function):
+    """act(conv(cat(inputs), weight) + bias).  cfg = (k, stride, pad, opad, transposed, act, alpha, beta, out_hw)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, cfg, *inputs):
+        k, stride, pad, opad, transposed, act, alpha, beta, out_hw = cfg
+        inputs = [_c(x) for x in inputs]
+        weight = _c(weight)
+        bias = _c(bias) if bias is not None else None
+        N, _, H, W = inputs[0].shape
+        segc = [int(x.shape[1]) for x in inputs]
+        for x in inputs:
+            if x.shape[0] != N or x.shape[2] != H or x.shape[3] != W:
+                raise ValueError(f"virtual concat needs equal N,H,W; got {[tuple(t.shape) for t in inputs]}")
+        cin = sum(segc)
+        cout = weight.shape[1] if transposed else weight.shape[0]
+        if (weight.shape[0] if transposed else weight.shape[1]) != cin:
+            raise ValueError(f"weight {tuple(weight.shape)} does not match {cin} input channels")
+        oh, ow = conv_out_size(H, k, stride, pad, opad, transposed), conv_out_size(W, k, stride, pad, opad, transposed)
+        if out_hw is not None:                              # crop_like folded into the kernel
+            oh, ow = min(oh, out_hw[0]), min(ow, out_hw[1])
+        desc = L.ConvDesc(N, cin, H, W, cout, oh, ow, k, k, stride, pad, 1 if transposed else 0, act, alpha, beta)
+        out = torch.empty((N, cout, oh, ow), device=weight.device, dtype=torch.float32)
+        L.check(L.lib().dvf_conv2d_fwd(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc), len(segc),
+                                       L.dev(weight, "weight"), L.dev(bias, "bias"), L.dev(out), L.stream()),
+                "dvf_conv2d_fwd")
+        ctx.save_for_backward(weight, out, *inputs)
+        ctx.desc, ctx.segc, ctx.has_bias = desc, segc, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        weight, out, *inputs = ctx.saved_tensors
+        desc, segc = ctx.desc, ctx.segc
+        lib = L.lib()
+        gout = _c(gout)
+        N, cout, oh, ow = out.shape
+        need_w, need_b = ctx.needs_input_grad[0], ctx.has_bias and ctx.needs_input_grad[1]
+        need_in = list(ctx.needs_input_grad[3:])
+        dbias = torch.empty(cout, device=out.device) if need_b else None
+        if desc.act != L.ACT_NONE:
+            dpre = torch.empty_like(gout)
+            L.check(lib.dvf_act_bwd(L.dev(gout, "grad_out"), L.dev(out), L.dev(dpre), L.dev(dbias), N, cout, oh * ow,
+                                    desc.act, desc.alpha, desc.beta, L.stream()), "dvf_act_bwd")
+        else:
+            dpre = gout
+            if need_b:
+                L.check(lib.dvf_act_bwd(L.dev(gout), None, None, L.dev(dbias), N, cout, oh * ow, L.ACT_NONE, 1.0, 0.0,
+                                        L.stream()), "dvf_act_bwd")
+        gins = [torch.empty_like(x) if need else None for x, need in zip(inputs, need_in)]
+        if any(need_in):
+            L.check(lib.dvf_conv2d_dgrad(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins), L.int_array(segc),
+                                         len(segc), L.stream()), "dvf_conv2d_dgrad")
+        dw = None
+        if need_w:
+            dw = torch.empty_like(weight)
+            L.check(lib.dvf_conv2d_wgrad(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
+                                         L.dev(dpre), L.dev(dw), 0, L.stream()), "dvf_conv2d_wgrad")
+        return (dw, dbias, None, *gins)
+
+
+class Upsample2xFn(torch.autograd.Function):
+    """F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) followed by crop_like to out_hw
+    (reference DispNetS.py:115,121,127)."""
+
+    @staticmethod
+    def forward(ctx, x, out_hw):
+        x = _c(x)
+        N, C, H, W = x.shape
+        oh, ow = min(2 * H, out_hw[0]), min(2 * W, out_hw[1])
+        out = torch.empty((N, C, oh, ow), device=x.device, dtype=torch.float32)
+        L.check(L.lib().dvf_resize_bilinear_fwd(L.dev(x, "input"), L.dev(out), N * C, H, W, oh, ow, 0.5, 0.5, L.stream()),
+                "dvf_resize_bilinear_fwd")
+        ctx.shape = (N, C, H, W, oh, ow)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        N, C, H, W, oh, ow = ctx.shape
+        gin = torch.empty((N, C, H, W), device=gout.device, dtype=torch.float32)
+        L.check(L.lib().dvf_upsample2x_bwd(L.dev(_c(gout), "grad_out"), L.dev(gin), N * C, H, W, oh, ow, L.stream()),
+                "dvf_upsample2x_bwd")
+        return gin, None
+
+
+class RecipFn(torch.autograd.Function):
+    """1 / (x + eps): disparity -> depth (train.py:188 with eps=0, unsupervise.py:99 with eps=1e-4)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = _c(x)
+        y = torch.empty_like(x)
+        L.check(L.lib().dvf_recip_fwd(L.dev(x, "input"), L.dev(y), eps, x.numel(), L.stream()), "dvf_recip_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gx = torch.empty_like(y)
+        L.check(L.lib().dvf_recip_bwd(L.dev(_c(gy), "grad_out"), L.dev(y), L.dev(gx), y.numel(), L.stream()),
+                "dvf_recip_bwd")
+        return gx, None
+
+
+class SpatialMeanFn(torch.autograd.Function):
+    """scale * x.mean(3).mean(2)  (PoseExpNet_sfm.py:72-73)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _c(x)
+        N, C, H, W = x.shape
+        out = torch.empty((N, C), device=x.device, dtype=torch.float32)
+        L.check(L.lib().dvf_spatial_mean_fwd(L.dev(x, "input"), L.dev(out), N * C, H * W, scale, L.stream()),
+                "dvf_spatial_mean_fwd")
+        ctx.shape, ctx.scale = (N, C, H, W), scale
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        N, C, H, W = ctx.shape
+        gin = torch.empty((N, C, H, W), device=gout.device, dtype=torch.float32)
+        L.check(L.lib().dvf_spatial_mean_bwd(L.dev(_c(gout), "grad_out"), L.dev(gin), N * C, H * W, ctx.scale,
+                                             L.stream()), "dvf_spatial_mean_bwd")
+        return gin, None
+
+
+def reciprocal(x, eps=0.0):
+    return RecipFn.apply(x, float(eps))
+
+
+def area_downsample(x, out_hw):
+    """F.interpolate(x, out_hw, mode='area') for inputs that need no gradient (images)."""
+    x = _c(x)
+    N, C, H, W = x.shape
+    if (H, W) == tuple(out_hw):
+        return x
+    out = torch.empty((N, C, out_hw[0], out_hw[1]), device=x.device, dtype=torch.float32)
+    L.check(L.lib().dvf_area_downsample(L.dev(x, "input"), L.dev(out), N * C, H, W, out_hw[0], out_hw[1], L.stream()),
+            "dvf_area_downsample")
+    return out
+
+
+def bilinear_half(x):
+    """F.interpolate(x, scale_factor=0.5, mode='bilinear') for inputs that need no gradient (images)."""
+    x = _c(x)
+    N, C, H, W = x.shape
+    oh, ow = H // 2, W // 2
+    out = torch.empty((N, C, oh, ow), device=x.device, dtype=torch.float32)
+    L.check(L.lib().dvf_resize_bilinear_fwd(L.dev(x, "input"), L.dev(out), N * C, H, W, oh, ow, 2.0, 2.0, L.stream()),
+            "dvf_resize_bilinear_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ module shells
+
+class FusedConv2d(nn.Module):
+    """nn.Conv2d (+ fused activation) with torch's parameter layout [C_out, C_in, k, k]."""
+    transposed = False
+
+    def __init__(self, in_planes, out_planes, kernel_size, stride=1, padding=0, act=L.ACT_NONE, alpha=1.0, beta=0.0,
+                 output_padding=0):
+        super().__init__()
+        self.k, self.stride, self.pad, self.opad = kernel_size, stride, padding, output_padding
+        self.act, self.alpha, self.beta = act, float(alpha), float(beta)
+        self.in_planes, self.out_planes = in_planes, out_planes
+        shape = (in_planes, out_planes) if self.transposed else (out_planes, in_planes)
+        self.weight = nn.Parameter(torch.empty(*shape, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_planes))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # torch's default Conv2d init (kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in)))
+        fan_in = self.weight.shape[1] * self.k * self.k
+        bound = 1.0 / math.sqrt(fan_in)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            self.bias.uniform_(-bound, bound)
+
+    def forward(self, *inputs, out_hw=None):
+        cfg = (self.k, self.stride, self.pad, self.opad, self.transposed, self.act, self.alpha, self.beta, out_hw)
+        return ConvFn.apply(self.weight, self.bias, cfg, *inputs)
+
+    def extra_repr(self):
+        return (f"{self.in_planes}, {self.out_planes}, kernel_size={self.k}, stride={self.stride}, padding={self.pad}, "
+                f"act={self.act}")
+
+
+class FusedConvTranspose2d(FusedConv2d):
+    """nn.ConvTranspose2d (+ fused activation), parameter layout [C_in, C_out, k, k]."""
+    transposed = True
+
+
+class FusedAct(nn.Module):
+    """Index placeholder: keeps the reference's nn.Sequential numbering (conv1.0 / conv1.2 ...) while the
+    activation itself runs in the epilogue of the preceding convolution kernel."""
+
+    def forward(self, x):
+        return x
+
+
+def xavier_init_(module):
+    """init_weights() of the reference nets: xavier_uniform_ on every conv weight, zero bias
+    (DispNetS.py:81-86, PoseExpNet_sfm.py:51-56, feat_extractor.py:85-90)."""
+    for m in module.modules():
+        if isinstance(m, FusedConv2d):
+            nn.init.xavier_uniform_(m.weight)
+            nn.init.zeros_(m.bias)

@@ -19,6 +19,18 @@ c_f = ctypes.c_float
 c_i64 = ctypes.c_int64
 c_pp = ctypes.POINTER(ctypes.c_void_p)   # host array of device pointers
 
+
+
+class ConvDesc(ctypes.Structure):
+    """struct dvf_conv_desc of include/dvf_hip.h"""
+    _fields_ = [(n, ctypes.c_int) for n in ("N", "C_in", "H_in", "W_in", "C_out", "H_out", "W_out", "KH", "KW",
+                                             "stride", "pad", "transposed", "act")] + \
+               [("alpha", ctypes.c_float), ("beta", ctypes.c_float)]
+
+
+c_desc = ctypes.POINTER(ConvDesc)
+c_ip = ctypes.POINTER(ctypes.c_int)
+
 ROT_QUAT, PAD_BORDER, ALIGN_CORNERS = 1, 2, 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID_AFFINE = 0, 1, 2
 MAX_VIEWS, MAX_SEGS = 4, 3
@@ -36,6 +48,18 @@ SIGNATURES = {
     "dvf_smooth_loss_fwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_f, c_i, c_fp]),
     "dvf_smooth_partials_floats": (c_i64, [c_i] * 3),
     "dvf_smooth_loss_bwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_f, c_fp]),
+    "dvf_conv2d_fwd": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "dvf_conv2d_dgrad": (c_i, [c_desc, c_fp, c_fp, c_pp, c_ip, c_i, c_fp]),
+    "dvf_conv2d_wgrad": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_i, c_fp]),
+    "dvf_act_bwd": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_fp]),
+    "dvf_resize_bilinear_fwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp]),
+    "dvf_upsample2x_bwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_fp]),
+    "dvf_recip_fwd": (c_i, [c_fp, c_fp, c_f, c_i64, c_fp]),
+    "dvf_recip_bwd": (c_i, [c_fp, c_fp, c_fp, c_i64, c_fp]),
+    "dvf_spatial_mean_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_f, c_fp]),
+    "dvf_spatial_mean_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_f, c_fp]),
+    "dvf_area_downsample": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_fp]),
+    "dvf_adam_step": (c_i, [c_fp] * 4 + [c_i64, c_fp, c_i] + [c_f] * 5 + [c_fp]),
 }
 
 
@@ -81,6 +105,10 @@ def ptr_array(tensors, name="tensors"):
     for i, t in enumerate(tensors):
         arr[i] = None if t is None else dev(t, f"{name}[{i}]").value
     return arr
+
+
+def int_array(vals):
+    return (ctypes.c_int * len(vals))(*vals)
 
 
 def geom_flags(rotation_mode="euler", padding_mode="zeros", align_corners=False):

@@ -96,6 +96,60 @@ int64_t dvf_smooth_partials_floats(int N, int H, int W);
 int dvf_smooth_loss_bwd(const float *map, const float *grad_loss, float *g_map, int N, int H, int W,
                         float weight, void *stream);
 
+/* ---------------------------------------------------------------- convolutions (fp32 MFMA)
+ * One descriptor for nn.Conv2d and nn.ConvTranspose2d as the reference's networks use them
+ * (DispNetS.py:7-34, PoseExpNet_sfm.py:6-17, feat_extractor.py:6-41): square-ish kernels up to 7x7,
+ * stride 1 or 2, symmetric padding, groups = 1.  H_out/W_out are the sizes actually kept, i.e. AFTER
+ * crop_like (DispNetS.py:37-39): the kernels never compute cropped-away pixels.
+ * Weight layouts are torch's: Conv2d [C_out,C_in,KH,KW]; ConvTranspose2d [C_in,C_out,KH,KW].
+ * The input may be a VIRTUAL CONCAT of up to DVF_MAX_SEGS tensors [N,seg_channels[i],H_in,W_in]
+ * (replaces torch.cat at DispNetS.py:98-128): in_segs / din_segs are HOST arrays of device pointers. */
+typedef struct dvf_conv_desc {
+    int N, C_in, H_in, W_in, C_out, H_out, W_out, KH, KW, stride, pad, transposed;
+    int act;           /* DVF_ACT_*: fused epilogue of the forward */
+    float alpha, beta; /* DVF_ACT_SIGMOID_AFFINE parameters */
+} dvf_conv_desc;
+
+/* out = act(conv(cat(in_segs), w) + bias).  Replaces nn.Conv2d / nn.ConvTranspose2d (+ReLU / Sigmoid, and the
+ * alpha*sigmoid+beta of DispNetS.py:112) forward.  bias may be NULL. */
+int dvf_conv2d_fwd(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                   const float *w, const float *bias, float *out, void *stream);
+/* d(loss)/d(input segment i) for i with din_segs[i] != NULL, given dpre = d(loss)/d(pre-activation output). */
+int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *const *din_segs,
+                     const int *seg_channels, int nseg, void *stream);
+/* d(loss)/d(w) in w's own layout; accumulate != 0 adds to dw, otherwise dw is zeroed first. */
+int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                     const float *dpre, float *dw, int accumulate, void *stream);
+/* Backward of the fused activation and of the bias in one pass: dpre = dy * act'(y) (y = the forward's
+ * output, [N,C,HW]); dbias[c] = sum dpre (zeroed by the call).  dpre or dbias may be NULL. */
+int dvf_act_bwd(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act,
+                float alpha, float beta, void *stream);
+
+/* ---------------------------------------------------------------- memory-bound helpers
+ * planes = N*C throughout. */
+/* F.interpolate(mode='bilinear', align_corners=False): out[Y][X] for Y<OH, X<OW with source scale
+ * scale_h = H/(full OH) (0.5 for x2 up, DispNetS.py:115,121,127 -- OH/OW may be the crop_like-cropped size;
+ * 2.0 for the x0.5 image pyramid of feat_extractor.py:44-46). */
+int dvf_resize_bilinear_fwd(const float *in, float *out, int planes, int H, int W, int OH, int OW, float scale_h,
+                            float scale_w, void *stream);
+/* backward of the x2 case (gather form, no atomics): gout [planes,OH,OW] -> gin [planes,H,W] */
+int dvf_upsample2x_bwd(const float *gout, float *gin, int planes, int H, int W, int OH, int OW, void *stream);
+/* y = 1 / (x + eps)  (train.py:188 eps=0; unsupervise.py:99 eps=1e-4) and its backward gx = -gy * y^2 */
+int dvf_recip_fwd(const float *x, float *y, float eps, int64_t n, void *stream);
+int dvf_recip_bwd(const float *gy, const float *y, float *gx, int64_t n, void *stream);
+/* out[plane] = scale * mean(in[plane])  (PoseExpNet_sfm.py:72-73: mean(3).mean(2) * 0.01) */
+int dvf_spatial_mean_fwd(const float *in, float *out, int planes, int HW, float scale, void *stream);
+int dvf_spatial_mean_bwd(const float *gout, float *gin, int planes, int HW, float scale, void *stream);
+/* F.interpolate(mode='area') = adaptive average pooling (loss_functions_sfm.py:18-19) */
+int dvf_area_downsample(const float *in, float *out, int planes, int H, int W, int OH, int OW, void *stream);
+/* torch.optim.Adam step (train.py:154-156, unsupervise.py:241) over a flat arena of n floats.
+ * opt_state: DEVICE float[4] = {step, lr, step_size, bc2_sqrt}; the caller initialises {0, lr, 0, 0}.
+ * advance_step != 0 increments step and refreshes the derived entries first (once per optimizer step).
+ * grad_scale multiplies the gradient (1/world_size after a sum all-reduce). */
+int dvf_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float *opt_state,
+                  int advance_step, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif
