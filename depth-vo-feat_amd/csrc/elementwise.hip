@@ -139,6 +139,38 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
     }
 }
 
+// explainability regulariser: BCE(mask, 1) = -mean(max(log m, -100))   (loss_functions_sfm.py:49-56)
+__global__ __launch_bounds__(256) void bce_ones_fwd_kernel(const float *m, float *partials, int64_t n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        s -= fmaxf(logf(m[i]), -100.f);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float *partials, int nblk, float scale, float *out,
+                                                           int accumulate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += partials[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+        out[0] = accumulate ? out[0] + t : t;
+    }
+}
+
+__global__ void bce_ones_bwd_kernel(const float *m, const float *grad_loss, float *gm, int64_t n) {
+    const float g = grad_loss[0] / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        gm[i] = (logf(m[i]) > -100.f) ? -g / m[i] : 0.f;
+}
+
 inline int nblocks(int64_t n) {
     const int64_t b = (n + 255) / 256;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -200,6 +232,24 @@ int dvf_area_downsample(const float *in, float *out, int planes, int H, int W, i
     if (!in || !out || planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return DVF_ERR_INVALID_ARG;
     const int64_t total = (int64_t)planes * OH * OW;
     area_down_kernel<<<nblocks(total), 256, 0, dvf_stream(stream)>>>(in, out, H, W, OH, OW, total);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+int dvf_bce_ones_fwd(const float *mask, float *loss_out, float *partials, int64_t n, int accumulate, void *stream) {
+    if (!mask || !loss_out || !partials || n <= 0) return DVF_ERR_INVALID_ARG;
+    hipStream_t st = dvf_stream(stream);
+    const int nb = nblocks(n) > 1024 ? 1024 : nblocks(n);
+    bce_ones_fwd_kernel<<<nb, 256, 0, st>>>(mask, partials, n);
+    DVF_LAUNCH_CHECK();
+    sum_partials_kernel<<<1, 256, 0, st>>>(partials, nb, 1.f / (float)n, loss_out, accumulate);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+int dvf_bce_ones_bwd(const float *mask, const float *grad_loss, float *g_mask, int64_t n, void *stream) {
+    if (!mask || !grad_loss || !g_mask || n <= 0) return DVF_ERR_INVALID_ARG;
+    bce_ones_bwd_kernel<<<nblocks(n), 256, 0, dvf_stream(stream)>>>(mask, grad_loss, g_mask, n);
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }

@@ -24,6 +24,9 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, bias, cfg, *inputs):
         k, stride, pad, opad, transposed, act, alpha, beta, out_hw = cfg
+        # parameters owned by a FlatAdam arena: their gradients are added in place (dvf/engine.py)
+        ctx.wparam = weight if getattr(weight, "_dvf_grad", None) is not None else None
+        ctx.bparam = bias if (bias is not None and getattr(bias, "_dvf_grad", None) is not None) else None
         inputs = [_c(x) for x in inputs]
         weight = _c(weight)
         bias = _c(bias) if bias is not None else None
@@ -73,9 +76,17 @@ class ConvFn(torch.autograd.Function):
                                          len(segc), L.stream()), "dvf_conv2d_dgrad")
         dw = None
         if need_w:
-            dw = torch.empty_like(weight)
+            arena = ctx.wparam is not None
+            dw = ctx.wparam._dvf_grad if arena else torch.empty_like(weight)
             L.check(lib.dvf_conv2d_wgrad(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
-                                         L.dev(dpre), L.dev(dw), 0, L.stream()), "dvf_conv2d_wgrad")
+                                         L.dev(dpre), L.dev(dw), 1 if arena else 0, L.stream()), "dvf_conv2d_wgrad")
+            if arena:
+                ctx.wparam._dvf_owner.grad_ready(ctx.wparam)
+                dw = None
+        if need_b and ctx.bparam is not None:
+            ctx.bparam._dvf_grad.add_(dbias)
+            ctx.bparam._dvf_owner.grad_ready(ctx.bparam)
+            dbias = None
         return (dw, dbias, None, *gins)
 
 

@@ -1,0 +1,179 @@
+"""Training-step engine: flat parameter / gradient / Adam-moment arenas in HBM, the fused Adam update,
+data-parallel gradient buckets (RCCL all-reduce launched from inside backward on a side stream) and HIP-graph
+capture of the whole step.
+
+Memory layout (one rank): every parameter of every network lives in ONE contiguous fp32 arena, in the order
+gradients become ready during backward (reverse registration order); gradients, exp_avg and exp_avg_sq are
+three more arenas with the same offsets.  ``param.data`` / ``param.grad`` are views, so ``state_dict``,
+checkpoints and user code see ordinary tensors, while
+  * the weight-gradient kernels add straight into the gradient arena (no per-parameter grad tensors),
+  * the all-reduce works on contiguous slices of it (no bucket copies),
+  * Adam is one kernel launch per contiguous run of parameters that received a gradient.
+Reference semantics kept: ``torch.optim.Adam`` as configured at train.py:150-156 / unsupervise.py:241,
+including "parameters without a gradient are skipped".
+"""
+import torch
+import torch.distributed as dist
+
+from . import lib as L
+
+
+class FlatAdam:
+    """torch.optim.Adam over flat arenas.  ``params``: iterable of nn.Parameter (all nets together)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world_size=1,
+                 bucket_mb=25.0, process_group=None):
+        self.params = [p for p in params if p.requires_grad][::-1]       # backward-ready order
+        if not self.params:
+            raise ValueError("no parameters")
+        dev = self.params[0].device
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
+        self.world_size, self.group = int(world_size), process_group
+        sizes = [p.numel() for p in self.params]
+        # 64-float (256 B) aligned offsets: every view starts on its own cache lines
+        self.offsets, off = [], 0
+        for n in sizes:
+            self.offsets.append(off)
+            off += (n + 63) // 64 * 64
+        self.total = off
+        self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_m = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_v = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.opt_state = torch.tensor([0.0, self.lr, 0.0, 0.0], device=dev, dtype=torch.float32)
+        for p, o, n in zip(self.params, self.offsets, sizes):
+            view = self.flat_p[o:o + n].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = None
+            p._dvf_grad = self.flat_g[o:o + n].view_as(p)     # wgrad kernels add straight into this
+            p._dvf_touched = False
+            p._dvf_owner = self
+        # gradient buckets = contiguous arena slices of ~bucket_mb, in backward order
+        self.buckets, cur_start, cur_params = [], 0, []
+        limit = int(bucket_mb * 1024 * 1024 / 4)
+        for i, (p, o, n) in enumerate(zip(self.params, self.offsets, sizes)):
+            cur_params.append(p)
+            end = o + (n + 63) // 64 * 64
+            if end - cur_start >= limit or i == len(self.params) - 1:
+                self.buckets.append({"start": cur_start, "end": end, "params": cur_params, "pending": 0})
+                cur_start, cur_params = end, []
+        for bi, b in enumerate(self.buckets):
+            for p in b["params"]:
+                p._dvf_bucket = bi
+        self._comm_stream = torch.cuda.Stream(device=dev) if (self.world_size > 1 and dev.type == "cuda") else None
+        self._ranges = None
+        self._reset_pending()
+
+    # ------------------------------------------------------------------ autograd side (called from ConvFn.backward)
+    def _reset_pending(self):
+        for b in self.buckets:
+            b["pending"] = sum(1 for p in b["params"] if p._dvf_touched or self._ranges is None)
+            b["launched"] = False
+
+    def grad_ready(self, p):
+        """A weight/bias gradient has been enqueued on the compute stream."""
+        if not p._dvf_touched:
+            p._dvf_touched = True
+            p.grad = p._dvf_grad            # expose it the torch way
+            self._ranges = None
+        if self.world_size <= 1:
+            return
+        b = self.buckets[p._dvf_bucket]
+        b["pending"] -= 1
+        if b["pending"] <= 0 and not b["launched"] and self._ranges is not None:
+            self._launch_bucket(b)
+
+    def _launch_bucket(self, b):
+        b["launched"] = True
+        grads = self.flat_g[b["start"]:b["end"]]
+        if self._comm_stream is None:                       # CPU tensors (gloo): synchronous
+            dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(ev)
+            dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
+
+    # ------------------------------------------------------------------ optimizer API
+    def zero_grad(self):
+        self.flat_g.zero_()
+        self._reset_pending()
+
+    def _touched_ranges(self):
+        if self._ranges is None:
+            rngs = []
+            for p, o in zip(self.params, self.offsets):
+                if not p._dvf_touched:
+                    continue
+                end = o + (p.numel() + 63) // 64 * 64
+                if rngs and rngs[-1][1] == o:
+                    rngs[-1][1] = end
+                else:
+                    rngs.append([o, end])
+            self._ranges = rngs
+        return self._ranges
+
+    def synchronize_grads(self):
+        """Finish the data-parallel exchange: launch what backward could not (first step, stragglers) and make the
+        compute stream wait for the side stream."""
+        if self.world_size <= 1:
+            return
+        self._touched_ranges()
+        for b in self.buckets:
+            if not b["launched"] and any(p._dvf_touched for p in b["params"]):
+                self._launch_bucket(b)
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    def step(self):
+        self.synchronize_grads()
+        lib = L.lib()
+        first = True
+        for o, e in self._touched_ranges():
+            L.check(lib.dvf_adam_step(L.dev(self.flat_p[o:e]), L.dev(self.flat_g[o:e]), L.dev(self.flat_m[o:e]),
+                                      L.dev(self.flat_v[o:e]), e - o, L.dev(self.opt_state), 1 if first else 0,
+                                      self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                      1.0 / self.world_size, L.stream()), "dvf_adam_step")
+            first = False
+
+    def set_lr(self, lr):
+        self.lr = float(lr)
+        self.opt_state[1:2].fill_(self.lr)
+
+    def state_dict(self):
+        return {"opt_state": self.opt_state.clone(), "exp_avg": self.flat_m.clone(), "exp_avg_sq": self.flat_v.clone(),
+                "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, sd):
+        self.opt_state.copy_(sd["opt_state"])
+        self.flat_m.copy_(sd["exp_avg"])
+        self.flat_v.copy_(sd["exp_avg_sq"])
+
+
+class GraphedStep:
+    """Capture ``fn(*static_inputs)`` -- a full forward + backward + optimizer step -- into a HIP graph after
+    ``warmup`` eager runs on a side stream, then replay it.  ``fn`` must return a tuple of tensors (losses);
+    new batches are copied into the static input tensors before each replay."""
+
+    def __init__(self, fn, static_inputs, warmup=2):
+        self.fn, self.inputs = fn, list(static_inputs)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                fn(*self.inputs)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = fn(*self.inputs)
+        self.eager_steps = warmup
+
+    def __call__(self, *new_inputs):
+        for dst, src in zip(self.inputs, new_inputs):
+            if src is not None and src is not dst:
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.outputs

@@ -125,3 +125,32 @@ class SmoothLossFn(torch.autograd.Function):
                                                 L.stream()), "dvf_smooth_loss_bwd")
             grads.append(g)
         return (None, *grads)
+
+
+class ExplainabilityLossFn(torch.autograd.Function):
+    """explainability_loss over a list of masks (reference loss_functions_sfm.py:49-56)."""
+
+    @staticmethod
+    def forward(ctx, *masks):
+        masks = [_f32c(m) for m in masks]
+        out = torch.empty(1, device=masks[0].device)
+        partials = torch.empty(1024, device=masks[0].device)
+        for i, m in enumerate(masks):
+            L.check(L.lib().dvf_bce_ones_fwd(L.dev(m, "mask"), L.dev(out), L.dev(partials), m.numel(), 1 if i > 0 else 0,
+                                             L.stream()), "dvf_bce_ones_fwd")
+        ctx.save_for_backward(*masks)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        gl = _f32c(gloss).reshape(1)
+        grads = []
+        for i, m in enumerate(ctx.saved_tensors):
+            if not ctx.needs_input_grad[i]:
+                grads.append(None)
+                continue
+            g = torch.empty_like(m)
+            L.check(L.lib().dvf_bce_ones_bwd(L.dev(m), L.dev(gl, "grad_loss"), L.dev(g), m.numel(), L.stream()),
+                    "dvf_bce_ones_bwd")
+            grads.append(g)
+        return tuple(grads)

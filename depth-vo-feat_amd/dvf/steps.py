@@ -1,0 +1,55 @@
+"""The training-step bodies of the reference's entry scripts, on the HIP path.
+
+  unsupervise_losses  unsupervise.py:83-111   img recon + 10*smooth (+ 0.1*feature recon), single scale
+  train_sfm_losses    train.py:179-203        4-scale photometric with masks + w3*smooth + stereo-pose MSE
+Each returns (total_loss, dict of detached per-term losses); the caller does zero_grad / backward / step.
+No ``.item()`` here: the reference's 5 host syncs per step (train.py:205-209) are left to the logger."""
+import torch
+
+import loss_functions as LF
+import loss_functions_sfm as LS
+from dvf.conv import reciprocal
+
+
+def unsupervise_losses(depth_net, pose_net, batch, feat_extractor=None, img_scale=0.004, smooth_weight=10.0,
+                       feat_weight=0.1, depth_eps=1e-4):
+    R2, R1, L2 = batch["img_R2"], batch["img_R1"], batch["img_L2"]
+    inv_depth = depth_net(R2)[0]                                   # unsupervise.py:94 (intended: finest disparity)
+    _, T_2to1 = pose_net((R2, R1))                                 # :92,95   cat(R2, R1) done virtually
+    depth = reciprocal(inv_depth, depth_eps).squeeze(1)            # :99
+    img_loss = LF.photometric_reconstruction_loss(img_scale * R2, img_scale * R1, img_scale * L2, depth, T_2to1,
+                                                  batch["T_R2L"], batch["K"], batch["Kinv"])       # :101
+    smooth = LF.smooth_loss(depth.unsqueeze(1))                    # :102
+    terms = {"img": img_loss.detach(), "smooth": smooth.detach()}
+    loss = img_loss + smooth_weight * smooth
+    if feat_extractor is not None:
+        b = R2.size(0)
+        feat = feat_extractor(torch.cat((L2, R2, R1), dim=0))      # :104-105
+        f_L2, f_R2, f_R1 = feat[:b], feat[b:2 * b], feat[2 * b:]  # :107
+        feat_loss = LF.photometric_reconstruction_loss(f_R2, f_R1, f_L2, depth, T_2to1, batch["T_R2L"], batch["K"],
+                                                       batch["Kinv"])                              # :109
+        loss = img_loss + feat_weight * feat_loss + smooth_weight * smooth                          # :111
+        terms["feat"] = feat_loss.detach()
+    terms["total"] = loss.detach()
+    return loss, terms
+
+
+def train_sfm_losses(disp_net, pose_exp_net, batch, w1=1.0, w2=0.0, w3=0.1, smooth_factor=2.0,
+                     rotation_mode="euler", padding_mode="zeros"):
+    tgt = batch["img_R2"]
+    refs = [batch["img_R1"], batch["img_L2"]] + list(batch.get("extra_refs", []))[: pose_exp_net.nb_ref_imgs - 2]
+    disparities = disp_net(tgt)                                    # train.py:187
+    depth = [reciprocal(d, 0.0) for d in disparities]              # :188
+    masks, pose = pose_exp_net(tgt, refs)                          # :189
+    l1 = LS.photometric_reconstruction_loss(tgt, refs, batch["K"], batch["Kinv"], depth, masks, pose,
+                                            rotation_mode, padding_mode)                           # :191
+    l3 = LS.smooth_loss(depth, smooth_factor)                      # :200
+    l4 = torch.nn.functional.mse_loss(pose[:, 1], batch["T_R2L"])  # :201  (24 floats: left to torch)
+    loss = w1 * l1 + w3 * l3 + l4
+    terms = {"photo": l1.detach(), "smooth": l3.detach(), "lr": l4.detach()}
+    if w2 > 0:
+        l2 = LS.explainability_loss(masks)                         # :195-196
+        loss = loss + w2 * l2
+        terms["exp"] = l2.detach()
+    terms["total"] = loss.detach()
+    return loss, terms

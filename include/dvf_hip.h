@@ -142,6 +142,10 @@ int dvf_spatial_mean_fwd(const float *in, float *out, int planes, int HW, float 
 int dvf_spatial_mean_bwd(const float *gout, float *gin, int planes, int HW, float scale, void *stream);
 /* F.interpolate(mode='area') = adaptive average pooling (loss_functions_sfm.py:18-19) */
 int dvf_area_downsample(const float *in, float *out, int planes, int H, int W, int OH, int OW, void *stream);
+/* explainability_loss of one scale (loss_functions_sfm.py:49-56): loss_out[0] (+)= -mean(max(log mask, -100));
+ * partials: workspace of >= 1024 floats.  Backward: g_mask = -grad_loss / (n * mask). */
+int dvf_bce_ones_fwd(const float *mask, float *loss_out, float *partials, int64_t n, int accumulate, void *stream);
+int dvf_bce_ones_bwd(const float *mask, const float *grad_loss, float *g_mask, int64_t n, void *stream);
 /* torch.optim.Adam step (train.py:154-156, unsupervise.py:241) over a flat arena of n floats.
  * opt_state: DEVICE float[4] = {step, lr, step_size, bc2_sqrt}; the caller initialises {0, lr, 0, 0}.
  * advance_step != 0 increments step and refreshes the derived entries first (once per optimizer step).

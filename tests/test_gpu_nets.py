@@ -1,0 +1,183 @@
+"""GPU parity of the drop-in networks and of whole training steps against the reference's golden vectors
+(tests/golden/net_*.npz, step_*.npz) and against the CPU oracle.  fp32, 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, t
+from oracle import nets as onets
+from oracle import steps as osteps
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda"
+
+
+def _load(module, sd):
+    res = module.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return module.to(DEV)
+
+
+def _check_digest(g, grads, prefix=""):
+    keys = [str(k) for k in g[prefix + "keys"]]
+    assert sorted(grads) == keys
+    for i, k in enumerate(keys):
+        gr = grads[k].detach().double().cpu()
+        scale = max(float(g[prefix + "norms"][i]), 1e-12)
+        assert abs(float(gr.norm()) - float(g[prefix + "norms"][i])) / scale < TOL, k
+        n = min(8, gr.numel())
+        assert np.abs(gr.flatten()[:n].numpy() - g[prefix + "heads"][i][:n]).max() / scale < TOL, k
+
+
+def test_dispnet_golden():
+    import DispNetS
+    g = load_golden("net_dispnet")
+    net = _load(DispNetS.DispNetS(), onets.fill_params(onets.dispnet_layers(), seed=1))
+    net.train()
+    outs = net(t(g["x"], DEV))
+    assert len(outs) == 4
+    for i, o in enumerate(outs):
+        assert tuple(o.shape) == g[f"out{i}"].shape
+        assert rel_err(o, g[f"out{i}"]) < TOL, f"disp{i + 1}"
+    sum((o * t(g[f"wt{i}"], DEV)).sum() for i, o in enumerate(outs)).backward()
+    _check_digest(g, {k: p.grad for k, p in net.named_parameters()})
+
+
+@pytest.mark.parametrize("tag", ["sfm", "six"])
+def test_posenet_golden(tag):
+    g = load_golden(f"net_posenet_{tag}")
+    x = t(g["x"], DEV)
+    if tag == "sfm":
+        import PoseExpNet_sfm
+        net = _load(PoseExpNet_sfm.PoseExpNet(nb_ref_imgs=2, output_exp=True),
+                    onets.fill_params(onets.posenet_layers(9, 12, 2, True), seed=2))
+        args = (x[:, :3].contiguous(), [x[:, 3:6].contiguous(), x[:, 6:9].contiguous()])
+    else:
+        import PoseExpNet
+        net = _load(PoseExpNet.PoseExpNet(output_exp=True), onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2))
+        args = (x,)
+    net.train()
+    masks, pose = net(*args)
+    assert rel_err(pose, g["pose"]) < TOL
+    for i, m in enumerate(masks):
+        assert rel_err(m, g[f"mask{i}"]) < TOL
+    ((pose * t(g["wp"], DEV)).sum() * 100 + sum((m * t(g[f"wm{i}"], DEV)).sum() for i, m in enumerate(masks))).backward()
+    _check_digest(g, {k: p.grad for k, p in net.named_parameters()})
+    net.eval()
+    with torch.no_grad():
+        m1, _ = net(*args)
+    assert torch.is_tensor(m1)          # eval mode returns only the finest mask (PoseExpNet_sfm.py:92-95)
+
+
+def _check_params(g, name, module, lr, n_steps=2):
+    sd = {k: v.detach().double().cpu() for k, v in module.state_dict().items()}
+    keys = [str(k) for k in g[f"p_{name}_keys"]]
+    assert sorted(sd) == keys
+    for i, k in enumerate(keys):
+        n = float(g[f"p_{name}_norms"][i])
+        assert abs(float(sd[k].norm()) - n) / max(n, 1e-12) < TOL, k
+        flip = 2 * lr * n_steps * (1 + 1e-3 * sd[k].numel())     # see tests/test_oracle_golden.py::_check_params
+        assert abs(float(sd[k].sum()) - float(g[f"p_{name}_sums"][i])) < TOL * n + flip, k
+
+
+def _batch(b, h, w):
+    from dvf.synthetic import synthetic_batch
+    prod = synthetic_batch(b, h, w, seed=1234, device=DEV)
+    ref = osteps.synthetic_batch(b, h, w, seed=1234)
+    for k in ("img_R2", "img_R1", "img_L2", "K", "Kinv", "T_R2L"):     # product recipe == oracle recipe
+        assert torch.equal(prod[k].cpu(), ref[k])
+    return prod
+
+
+def test_step_unsupervise_golden():
+    """Two full iterations of the unsupervise.py body (cfg 2 family) with FlatAdam, vs the reference run."""
+    import DispNetS
+    import PoseExpNet
+    from dvf.engine import FlatAdam
+    from dvf.steps import unsupervise_losses
+    g = load_golden("step_unsup")
+    b, h, w = int(g["b"]), int(g["h"]), int(g["w"])
+    batch = _batch(b, h, w)
+    disp = _load(DispNetS.DispNetS(), onets.fill_params(onets.dispnet_layers(), seed=1))
+    pose = _load(PoseExpNet.PoseExpNet(output_exp=True), onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2))
+    disp.train(); pose.train()
+    opt = FlatAdam(list(pose.parameters()) + list(disp.parameters()), lr=1e-3, weight_decay=1e-8)
+    for it in range(2):
+        loss, terms = unsupervise_losses(disp, pose, batch)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            _check_digest(g, {k: p.grad for k, p in disp.named_parameters() if p.grad is not None}, "g_disp_")
+            _check_digest(g, {k: p.grad for k, p in pose.named_parameters() if p.grad is not None}, "g_pose_")
+        opt.step()
+        assert rel_err(terms["img"], g[f"img{it}"]) < TOL
+        assert rel_err(terms["smooth"], g[f"smooth{it}"]) < TOL
+        assert rel_err(terms["total"], g[f"total{it}"]) < TOL
+    _check_params(g, "disp", disp, 1e-3)
+    _check_params(g, "pose", pose, 1e-3)
+
+
+def test_step_train_sfm_golden():
+    """Two full iterations of the train.py body (4 scales, masks, smooth, stereo-pose MSE)."""
+    import DispNetS
+    import PoseExpNet_sfm
+    from dvf.engine import FlatAdam
+    from dvf.steps import train_sfm_losses
+    g = load_golden("step_train_sfm")
+    b, h, w = int(g["b"]), int(g["h"]), int(g["w"])
+    batch = _batch(b, h, w)
+    disp = _load(DispNetS.DispNetS(), onets.fill_params(onets.dispnet_layers(), seed=1))
+    pose = _load(PoseExpNet_sfm.PoseExpNet(nb_ref_imgs=2, output_exp=True),
+                 onets.fill_params(onets.posenet_layers(9, 12, 2, True), seed=2))
+    disp.train(); pose.train()
+    opt = FlatAdam(list(disp.parameters()) + list(pose.parameters()), lr=2e-4)
+    for it in range(2):
+        loss, terms = train_sfm_losses(disp, pose, batch)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            _check_digest(g, {k: p.grad for k, p in disp.named_parameters() if p.grad is not None}, "g_disp_")
+            _check_digest(g, {k: p.grad for k, p in pose.named_parameters() if p.grad is not None}, "g_pose_")
+        opt.step()
+        for k in ("photo", "smooth", "lr", "total"):
+            assert rel_err(terms[k], g[f"{k}{it}"]) < TOL, k
+    _check_params(g, "disp", disp, 2e-4)
+    _check_params(g, "pose", pose, 2e-4)
+
+
+def test_graphed_step_matches_eager():
+    """The HIP-graph replay of a whole step produces the same losses and parameters as eager execution."""
+    import DispNetS
+    import PoseExpNet
+    from dvf.engine import FlatAdam, GraphedStep
+    from dvf.steps import unsupervise_losses
+    b, h, w = 1, 64, 128
+    batch = _batch(b, h, w)
+    results = []
+    for graphed in (False, True):
+        disp = _load(DispNetS.DispNetS(), onets.fill_params(onets.dispnet_layers(), seed=1))
+        pose = _load(PoseExpNet.PoseExpNet(output_exp=True), onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2))
+        opt = FlatAdam(list(pose.parameters()) + list(disp.parameters()), lr=1e-3, weight_decay=1e-8)
+
+        def step():
+            loss, terms = unsupervise_losses(disp, pose, batch)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return (terms["total"],)
+
+        if graphed:
+            runner = GraphedStep(step, [], warmup=2)       # 2 eager steps, then capture (enqueues nothing)
+            losses = [float(runner()[0]) for _ in range(2)]  # replays = steps 3 and 4
+        else:
+            losses = [float(step()[0]) for _ in range(4)][2:]
+        torch.cuda.synchronize()
+        results.append((losses, opt.flat_p.clone()))
+    (l0, p0), (l1, p1) = results
+    assert max(abs(a - b) / abs(a) for a, b in zip(l0, l1)) < 1e-4
+    # Parameters: float atomics make gradients differ by ~1e-7 relative from run to run (eager vs eager too), and
+    # Adam's first steps move an element by lr * g/(|g| + eps), which is O(lr) sensitive where |g| ~ eps = 1e-8.
+    # So: every element within the hard bound 2*lr per step, and the parameter vector as a whole equal to 1e-3.
+    assert float((p1 - p0).abs().max()) <= 2 * 1e-3 * 4
+    assert float((p1 - p0).norm() / p0.norm()) < 1e-3
