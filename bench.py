@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: KITTI 256x832 stereo-sequence training samples/sec (forward + backward + Adam) of the
+DispNetS + PoseExpNet joint step (BASELINE.json configs[1], SURVEY.md section 8d cfg 2), synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RCCL = torch.distributed backend "nccl"); weak scaling: every rank runs batch 4, gradients
+are sum-all-reduced over flat arena buckets during backward and averaged inside the fused Adam.  Rank 0 prints
+ONE JSON line.  `value` counts samples of all ranks over the slowest rank's time.  Besides the contract keys the
+line carries `roofline` (dominant kernel = the fp32-MFMA gather convolution, measured live with HIP events),
+`roofline_warp` (fused warp+photometric kernels vs HBM) and `cpu_baseline` (the CPU oracle of the same step,
+timed on this host's cores on a bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "depth-vo-feat_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+
+
+def build(args, device, world):
+    import DispNetS
+    import PoseExpNet
+    from dvf.engine import FlatAdam
+    from dvf.steps import unsupervise_losses
+    from dvf.synthetic import synthetic_batch
+    torch.manual_seed(args.seed)
+    disp_net = DispNetS.DispNetS()
+    pose_net = PoseExpNet.PoseExpNet(output_exp=True)
+    disp_net.init_weights()
+    pose_net.init_weights()
+    disp_net.to(device).train()
+    pose_net.to(device).train()
+    rank = dist.get_rank() if world > 1 else 0
+    batch = synthetic_batch(args.batch, args.height, args.width, seed=1234, rank=rank, device=device)
+    # unsupervise.py:241  Adam(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)
+    opt = FlatAdam(list(pose_net.parameters()) + list(disp_net.parameters()), lr=1e-3, weight_decay=1e-8,
+                   world_size=world)
+
+    def step():
+        loss, terms = unsupervise_losses(disp_net, pose_net, batch)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return (terms["total"], terms["img"], terms["smooth"])
+
+    return step, opt
+
+
+def measure_kernels(step):
+    """One eager step with HIP-event brackets around every C-ABI call (dvf.lib.KernelTimer)."""
+    from dvf import lib as L
+    L.TIMER = L.KernelTimer()
+    step()
+    summ = L.TIMER.summary()
+    L.TIMER = None
+    return summ
+
+
+def host_cores():
+    """Cores this process may actually use: the cgroup CPU quota when there is one (the GPU box exposes 256
+    logical CPUs but grants a 16-CPU share), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(args):
+    """The CPU oracle (plain torch CPU restatement of the reference path, pinned to the reference by
+    tests/golden) running the SAME step body at the same resolution, batch 1, a few iterations."""
+    from oracle import nets as onets
+    from oracle import steps as osteps
+    nthreads = host_cores()
+    torch.set_num_threads(nthreads)
+    dsd = onets.fill_params(onets.dispnet_layers(), seed=1)
+    psd = onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2)
+    batch = osteps.synthetic_batch(1, args.height, args.width, seed=1234)
+    st = None
+    _, _, st = osteps.step_unsupervise(dsd, psd, batch, st)          # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 20):
+        _, _, st = osteps.step_unsupervise(dsd, psd, batch, st)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "samples/s", "cores": nthreads, "kind": "port",
+            "sample": f"{n} iterations of the same step (DispNetS+PoseExpNet, photometric V=2 + 10*smooth, Adam) at "
+                      f"{args.height}x{args.width}, batch 1, torch CPU fp32, {nthreads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (cfg 2: 4)")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=832)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    log("building models")
+    step, opt = build(args, device, world)
+    use_graph = (world == 1) and not args.no_graph
+    from dvf.engine import GraphedStep
+    if use_graph:
+        log("eager step 1")
+        step()
+        torch.cuda.synchronize()
+        log("capturing HIP graph")
+        runner = GraphedStep(step, [], warmup=1)
+        run = runner
+    else:
+        run = step
+    log("warm-up")
+    for _ in range(args.warmup):
+        out = run()
+    torch.cuda.synchronize()
+    log("timing")
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = float(out[0])
+
+    result = None
+    if rank == 0:
+        samples = args.batch * world * args.steps
+        result = {
+            "metric": "KITTI 256x832 stereo-seq samples/sec fwd+bwd", "value": samples / dt, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: DispNetS+PoseExpNet joint step, spatial+temporal photometric (V=2) + "
+                                   "10*smooth, Adam; %dx%d, batch %d per GPU" % (args.height, args.width, args.batch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "launch": "hipgraph" if use_graph else "eager"},
+            "final_loss": loss,
+        }
+    log("timed region done: %.2f ms/step" % (1e3 * dt / args.steps))
+    ks = None
+    if not args.no_kernel_timing:
+        # every rank runs the extra eager step (it contains the gradient all-reduce); rank 0 records
+        if rank == 0:
+            ks = measure_kernels(step)
+        else:
+            step()
+    if rank == 0 and ks is not None:
+        g_ms = ks.get("conv_fwd", {}).get("ms", 0) + ks.get("conv_dgrad", {}).get("ms", 0)
+        g_fl = ks.get("conv_fwd", {}).get("flops", 0) + ks.get("conv_dgrad", {}).get("flops", 0)
+        g_calls = ks.get("conv_fwd", {}).get("calls", 0) + ks.get("conv_dgrad", {}).get("calls", 0)
+        ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        result["roofline"] = {"kernel": "conv_gather_kernel (Conv2d/ConvTranspose2d forward + dgrad)", "bound": "mfma",
+                              "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "calls_per_step": g_calls,
+                              "ms_per_step": g_ms}
+        w = ks.get("conv_wgrad", {})
+        if w.get("ms", 0) > 0:
+            a = w["flops"] / (w["ms"] * 1e-3) / 1e12
+            result["roofline_wgrad"] = {"kernel": "conv_wgrad_kernel", "bound": "mfma", "achieved": a,
+                                        "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": a / PEAK_FP32_MFMA_TFLOPS,
+                                        "traffic": None, "calls_per_step": w["calls"], "ms_per_step": w["ms"]}
+        p_ms = ks.get("photo_fwd", {}).get("ms", 0) + ks.get("photo_bwd", {}).get("ms", 0)
+        p_by = ks.get("photo_fwd", {}).get("bytes", 0) + ks.get("photo_bwd", {}).get("bytes", 0)
+        if p_ms > 0:
+            a = p_by / (p_ms * 1e-3) / 1e9
+            result["roofline_warp"] = {"kernel": "photo_fwd_kernel + photo_bwd_kernel (fused warp + photometric L1)",
+                                       "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                       "frac": a / PEAK_HBM_GBPS, "traffic": None, "ms_per_step": p_ms}
+        result["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(ks.items())}
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline")
+        result["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

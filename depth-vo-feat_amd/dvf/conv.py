@@ -44,9 +44,13 @@ class ConvFn(torch.autograd.Function):
             oh, ow = min(oh, out_hw[0]), min(ow, out_hw[1])
         desc = L.ConvDesc(N, cin, H, W, cout, oh, ow, k, k, stride, pad, 1 if transposed else 0, act, alpha, beta)
         out = torch.empty((N, cout, oh, ow), device=weight.device, dtype=torch.float32)
-        L.check(L.lib().dvf_conv2d_fwd(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc), len(segc),
-                                       L.dev(weight, "weight"), L.dev(bias, "bias"), L.dev(out), L.stream()),
-                "dvf_conv2d_fwd")
+        # algorithmic MACs of this layer: kept pixels x taps actually contributing
+        taps = k * k / (stride * stride) if transposed else k * k
+        ctx.macs = float(N) * cout * oh * ow * cin * taps
+        with L.timed("conv_fwd", 2 * ctx.macs):
+            L.check(L.lib().dvf_conv2d_fwd(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc), len(segc),
+                                           L.dev(weight, "weight"), L.dev(bias, "bias"), L.dev(out), L.stream()),
+                    "dvf_conv2d_fwd")
         ctx.save_for_backward(weight, out, *inputs)
         ctx.desc, ctx.segc, ctx.has_bias = desc, segc, bias is not None
         return out
@@ -63,8 +67,9 @@ class ConvFn(torch.autograd.Function):
         dbias = torch.empty(cout, device=out.device) if need_b else None
         if desc.act != L.ACT_NONE:
             dpre = torch.empty_like(gout)
-            L.check(lib.dvf_act_bwd(L.dev(gout, "grad_out"), L.dev(out), L.dev(dpre), L.dev(dbias), N, cout, oh * ow,
-                                    desc.act, desc.alpha, desc.beta, L.stream()), "dvf_act_bwd")
+            with L.timed("act_bwd", 0.0, 12.0 * gout.numel()):
+                L.check(lib.dvf_act_bwd(L.dev(gout, "grad_out"), L.dev(out), L.dev(dpre), L.dev(dbias), N, cout, oh * ow,
+                                        desc.act, desc.alpha, desc.beta, L.stream()), "dvf_act_bwd")
         else:
             dpre = gout
             if need_b:
@@ -72,14 +77,17 @@ class ConvFn(torch.autograd.Function):
                                         L.stream()), "dvf_act_bwd")
         gins = [torch.empty_like(x) if need else None for x, need in zip(inputs, need_in)]
         if any(need_in):
-            L.check(lib.dvf_conv2d_dgrad(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins), L.int_array(segc),
-                                         len(segc), L.stream()), "dvf_conv2d_dgrad")
+            frac = sum(c for c, need in zip(segc, need_in) if need) / float(sum(segc))
+            with L.timed("conv_dgrad", 2 * ctx.macs * frac):
+                L.check(lib.dvf_conv2d_dgrad(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins),
+                                             L.int_array(segc), len(segc), L.stream()), "dvf_conv2d_dgrad")
         dw = None
         if need_w:
             arena = ctx.wparam is not None
             dw = ctx.wparam._dvf_grad if arena else torch.empty_like(weight)
-            L.check(lib.dvf_conv2d_wgrad(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
-                                         L.dev(dpre), L.dev(dw), 1 if arena else 0, L.stream()), "dvf_conv2d_wgrad")
+            with L.timed("conv_wgrad", 2 * ctx.macs):
+                L.check(lib.dvf_conv2d_wgrad(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
+                                             L.dev(dpre), L.dev(dw), 1 if arena else 0, L.stream()), "dvf_conv2d_wgrad")
             if arena:
                 ctx.wparam._dvf_owner.grad_ready(ctx.wparam)
                 dw = None

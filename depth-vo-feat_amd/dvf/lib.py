@@ -120,3 +120,58 @@ def geom_flags(rotation_mode="euler", padding_mode="zeros", align_corners=False)
         raise ValueError(f"padding_mode must be 'zeros' or 'border', got {padding_mode!r}")
     return ((ROT_QUAT if rotation_mode == "quat" else 0) | (PAD_BORDER if padding_mode == "border" else 0) |
             (ALIGN_CORNERS if align_corners else 0))
+
+
+class KernelTimer:
+    """Optional per-call timing with HIP events on the stream the kernels are launched on (torch's current
+    stream).  ``bench.py`` switches it on for one eager pass to measure per-kernel durations next to their
+    algorithmic FLOPs / bytes; it is off (None) otherwise and costs nothing."""
+
+    def __init__(self):
+        self.records = []       # (kind, start_event, stop_event, flops, bytes)
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def stop(self, kind, start_ev, flops=0.0, nbytes=0.0):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        self.records.append((kind, start_ev, ev, float(flops), float(nbytes)))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, a, b, fl, by in self.records:
+            d = out.setdefault(kind, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["calls"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+TIMER = None    # set to a KernelTimer() to record
+
+
+def timed(kind, flops=0.0, nbytes=0.0):
+    """Context manager: times the enclosed launches when TIMER is active."""
+    return _Timed(kind, flops, nbytes)
+
+
+class _Timed:
+    __slots__ = ("kind", "flops", "nbytes", "ev")
+
+    def __init__(self, kind, flops, nbytes):
+        self.kind, self.flops, self.nbytes, self.ev = kind, flops, nbytes, None
+
+    def __enter__(self):
+        if TIMER is not None:
+            self.ev = TIMER.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev is not None and TIMER is not None:
+            TIMER.stop(self.kind, self.ev, self.flops, self.nbytes)
+        return False

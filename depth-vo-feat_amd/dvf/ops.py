@@ -59,10 +59,14 @@ class PhotoLossFn(torch.autograd.Function):
         lib = L.lib()
         out = torch.empty(1 + V, device=tgt.device)
         partials = torch.empty(int(lib.dvf_photo_partials_floats(B, H, W, V)), device=tgt.device)
-        L.check(lib.dvf_photo_loss_fwd(L.dev(tgt, "tgt"), L.ptr_array(srcs, "srcs"), V, L.dev(depth, "depth"),
-                                       L.dev(pose, "pose"), L.dev(K, "intrinsics"), L.dev(Kinv, "intrinsics_inv"),
-                                       L.dev(mask, "mask"), L.dev(out), L.dev(out[1:]), L.dev(partials),
-                                       B, C, H, W, flags, L.stream()), "dvf_photo_loss_fwd")
+        # algorithmic bytes per target pixel: depth + C target + C*V sources (+ V masks)
+        fwd_bytes = float(B * H * W) * (4 + 4 * C + 4 * C * V + (4 * V if mask is not None else 0))
+        with L.timed("photo_fwd", 0.0, fwd_bytes):
+            L.check(lib.dvf_photo_loss_fwd(L.dev(tgt, "tgt"), L.ptr_array(srcs, "srcs"), V, L.dev(depth, "depth"),
+                                           L.dev(pose, "pose"), L.dev(K, "intrinsics"), L.dev(Kinv, "intrinsics_inv"),
+                                           L.dev(mask, "mask"), L.dev(out), L.dev(out[1:]), L.dev(partials),
+                                           B, C, H, W, flags, L.stream()), "dvf_photo_loss_fwd")
+        ctx.fwd_bytes = fwd_bytes
         ctx.save_for_backward(tgt, depth, pose, K, Kinv, mask, *srcs)
         ctx.flags = flags
         ctx.view_loss = out[1:]
@@ -82,10 +86,15 @@ class PhotoLossFn(torch.autograd.Function):
         g_srcs = [torch.zeros_like(s) if need[7 + i] else None for i, s in enumerate(srcs)]
         ws = torch.empty(int(lib.dvf_pose_ws_floats(V, B)), device=tgt.device) if need[2] else None
         gl = _f32c(gloss).reshape(1)
-        L.check(lib.dvf_photo_loss_bwd(L.dev(tgt), L.ptr_array(srcs), V, L.dev(depth), L.dev(pose), L.dev(K),
-                                       L.dev(Kinv), L.dev(mask), L.dev(gl, "grad_loss"), L.dev(g_depth),
-                                       L.dev(g_pose), L.dev(g_tgt), L.ptr_array(g_srcs), L.dev(g_mask), L.dev(ws),
-                                       B, C, H, W, ctx.flags, L.stream()), "dvf_photo_loss_bwd")
+        # bwd = fwd (recompute) + grad depth + mask grads + grad target + RMW scatter into the source grads
+        bwd_bytes = ctx.fwd_bytes + float(B * H * W) * (
+            (4 if g_depth is not None else 0) + (4 * V if g_mask is not None else 0) +
+            (4 * C if g_tgt is not None else 0) + 8 * C * sum(1 for g in g_srcs if g is not None))
+        with L.timed("photo_bwd", 0.0, bwd_bytes):
+            L.check(lib.dvf_photo_loss_bwd(L.dev(tgt), L.ptr_array(srcs), V, L.dev(depth), L.dev(pose), L.dev(K),
+                                           L.dev(Kinv), L.dev(mask), L.dev(gl, "grad_loss"), L.dev(g_depth),
+                                           L.dev(g_pose), L.dev(g_tgt), L.ptr_array(g_srcs), L.dev(g_mask), L.dev(ws),
+                                           B, C, H, W, ctx.flags, L.stream()), "dvf_photo_loss_bwd")
         return (g_tgt, g_depth, g_pose, None, None, g_mask, None, *g_srcs)
 
 
