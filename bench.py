@@ -64,6 +64,9 @@ def measure_kernels(step):
     L.TIMER = L.KernelTimer()
     step()
     summ = L.TIMER.summary()
+    if os.environ.get("DVF_LAYER_TABLE"):
+        for ms, kind, tag, tf, gb in L.TIMER.table()[:int(os.environ["DVF_LAYER_TABLE"])]:
+            print(f"  {ms:8.3f} ms  {kind:11s} {tf:7.2f} TF/s {gb:8.1f} GB/s  {tag}", file=sys.stderr)
     L.TIMER = None
     return summ
 

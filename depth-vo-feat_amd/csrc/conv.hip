@@ -23,6 +23,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+struct ClassDev { int py, px, by, bx, TA, TB, OHc, OWc, tap0; };
+
 struct GatherArgs {
     const float *in[DVF_MAX_SEGS];
     int segC[DVF_MAX_SEGS];
@@ -32,16 +34,16 @@ struct GatherArgs {
     int Mtot, Rtot, KK, m_base, M;
     const float *bias;   // indexed by m (already offset by the caller) or NULL
     float *out;          // [N, M, OH, OW]
-    int N, IH, IW, OH, OW, OHc, OWc;
-    int OS, py, px;      // output pixel (oy*OS+py, ox*OS+px)
-    int IS, by, bx;      // input  pixel (oy*IS+by+ta, ox*IS+bx+tb)
-    int TA, TB;
+    int N, IH, IW, OH, OW;
+    int OS, IS;          // output pixel (oy*OS+py, ox*OS+px); input pixel (oy*IS+by+ta, ox*IS+bx+tb)
+    int ncls;            // output-parity classes handled by this launch (blockIdx.z % ncls)
+    ClassDev cls[4];
     int act;
     float alpha, beta;
-    int CK, lck, KS, NCH, atomic_out;
+    int KS, NCH, atomic_out, dbg;
     int lsw, lsh, TGX, BW, BH, tilesX, tilesY;
-    int PH, PW, PWH, RS, PS, COTP;
-    int tapmap[49];
+    int PSmax, Tmax, WD; // LDS carve: patch CK*PSmax | weights Tmax*CK*COTP | wdec WD | tapB Tmax | inv 64
+    int tapmap[52];      // class c uses tapmap[cls[c].tap0 + t]: class tap -> tap index of the stored kernel
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float alpha, float beta) {
@@ -50,19 +52,48 @@ __device__ __forceinline__ float apply_act(float v, int act, float alpha, float 
     return v;
 }
 
-template <int MT, int NT>
+// MT x 32 output channels, 4*NT tiles of 32 pixels per block, CK = 2*CKH reduction channels per LDS chunk.
+template <int MT, int NT, int CKH>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
+    constexpr int CK = 2 * CKH, COTP = 32 * MT + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *patch = smem;                       // [CK][PH][RS] (IS==2: columns de-interleaved by parity)
-    float *wl = smem + a.CK * a.PS;            // [T][CK][COTP]
+    float *patch = smem;                                   // [CK][PH][RS] (IS==2: columns split by parity)
+    float *wl = smem + CK * a.PSmax;                       // [T][CK][COTP]
+    int *wdec = reinterpret_cast<int *>(wl + a.Tmax * CK * COTP);   // weight run element -> LDS offset
+    int *tapB = wdec + a.WD;                               // class tap -> patch offset
+    int *inv = tapB + a.Tmax;                              // stored tap -> class tap
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, kh = lane >> 5;
-    const int n = blockIdx.z / a.KS, ks = blockIdx.z - n * a.KS;
+    const int zc = blockIdx.z % a.ncls, zr = blockIdx.z / a.ncls;
+    const int n = zr / a.KS, ks = zr - n * a.KS;
+    const ClassDev c = a.cls[zc];
     const int tX = blockIdx.x % a.tilesX, tY = blockIdx.x / a.tilesX;
     const int oy0 = tY * a.BH, ox0 = tX * a.BW;
+    if (oy0 >= c.OHc || ox0 >= c.OWc) return;              // tile outside this (smaller) class: whole block exits
     const int m0 = blockIdx.y * (32 * MT);
     const int SW = 1 << a.lsw, SH = 1 << a.lsh;
     const int pxl = nl & (SW - 1), pyl = nl >> a.lsw;
-    const int T = a.TA * a.TB, CK = a.CK;
+    const int T = c.TA * c.TB;
+    const int PH = (a.BH - 1) * a.IS + c.TA, PW = (a.BW - 1) * a.IS + c.TB, PWH = (PW + 1) >> 1;
+    const int RS = (a.IS == 2) ? 2 * PWH : PW, PS = PH * RS;
+
+    // ---- one-time tables
+    for (int e = tid; e < 64; e += 256) inv[e] = -1;
+    __syncthreads();
+    for (int t = tid; t < T; t += 256) {
+        inv[a.tapmap[c.tap0 + t]] = t;
+        const int ta = t / c.TB, tb = t - ta * c.TB;
+        tapB[t] = ta * RS + ((a.IS == 2) ? ((tb & 1) * PWH + (tb >> 1)) : tb);
+    }
+    __syncthreads();
+    {
+        const int nE = (a.w_mode == 0 ? CK : 32 * MT) * a.KK;
+        for (int e = tid; e < nE; e += 256) {
+            const int hi = e / a.KK, t = inv[e - hi * a.KK];        // hi = r (mode 0) or m (mode 1)
+            int d = -1;
+            if (t >= 0) d = (hi << 24) | (a.w_mode == 0 ? (t * CK + hi) * COTP : t * CK * COTP + hi);
+            wdec[e] = d;
+        }
+    }
 
     int boff[NT], opy[NT], opx[NT];
 #pragma unroll
@@ -70,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
         const int q = wave * NT + i, tx = q % a.TGX, ty = q / a.TGX;
         opy[i] = ty * SH + pyl;
         opx[i] = tx * SW + pxl;
-        boff[i] = kh * a.PS + (opy[i] * a.IS) * a.RS + opx[i];
+        boff[i] = kh * PS + (opy[i] * a.IS) * RS + opx[i];
     }
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -80,82 +111,141 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
 
-    const int iy0 = oy0 * a.IS + a.by, ix0 = ox0 * a.IS + a.bx;
+    const int iy0 = oy0 * a.IS + c.by, ix0 = ox0 * a.IS + c.bx;
     const int g_begin = (int)(((int64_t)a.NCH * ks) / a.KS), g_end = (int)(((int64_t)a.NCH * (ks + 1)) / a.KS);
-    // walk the chunks of the (virtually concatenated) input segments
     int seg = 0, seg_first = 0, r_seg = 0;     // r_seg: index of the segment's first channel in the concat
     for (int g = g_begin; g < g_end; ++g) {
         while (true) {
-            const int nchs = (a.segC[seg] + CK - 1) >> a.lck;
+            const int nchs = (a.segC[seg] + CK - 1) / CK;
             if (g < seg_first + nchs) break;
             seg_first += nchs;
             r_seg += a.segC[seg];
             ++seg;
         }
-        const int c0 = (g - seg_first) << a.lck;              // first channel of the chunk inside its segment
+        const int c0 = (g - seg_first) * CK;                  // first channel of the chunk inside its segment
         const int nch = min(CK, a.segC[seg] - c0);            // valid channels in this chunk
         const float *src = a.in[seg] + ((int64_t)n * a.segC[seg] + c0) * a.IH * a.IW;
-        __syncthreads();                                      // previous chunk fully consumed
-        // ---- stage the input patch
-        {
-            int ci = 0, r = wave;
-            while (r >= a.PH) { r -= a.PH; ++ci; }
-            while (ci < CK) {
-                const int iy = iy0 + r;
-                const bool rowok = (ci < nch) && (iy >= 0) && (iy < a.IH);
-                const float *rp = src + ((int64_t)ci * a.IH + iy) * a.IW;
-                float *dp = patch + ci * a.PS + r * a.RS;
-                for (int c = lane; c < a.PW; c += 64) {
-                    const int ix = ix0 + c;
-                    const float v = (rowok && ix >= 0 && ix < a.IW) ? rp[ix] : 0.f;
-                    const int pos = (a.IS == 2) ? ((c & 1) * a.PWH + (c >> 1)) : c;
-                    dp[pos] = v;
+        __syncthreads();                                      // previous chunk fully consumed (and tables visible)
+        // ---- stage the input patch.  Unit = (patch row, 64-column pass); each wave takes every 4th unit and
+        // issues 8 independent global loads before the 8 LDS stores (a load -> store -> load chain would expose
+        // the full memory latency once per row).
+        if (!(a.dbg & 1)) {
+            const int lnp = (PW > 64) ? 1 : 0, units = (CK * PH) << lnp;
+            for (int ub = wave; ub < units; ub += 32) {
+                float v[8];
+                int dst[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int u = ub + 4 * k;
+                    v[k] = 0.f;
+                    dst[k] = -1;
+                    if (u < units) {
+                        const int row = u >> lnp, cc = lane + ((u & lnp) << 6);
+                        const int ci = row / PH, r = row - ci * PH;
+                        if (cc < PW) {
+                            const int iy = iy0 + r, ix = ix0 + cc;
+                            dst[k] = ci * PS + r * RS + ((a.IS == 2) ? ((cc & 1) * PWH + (cc >> 1)) : cc);
+                            if (ci < nch && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
+                                v[k] = src[((int64_t)ci * a.IH + iy) * a.IW + ix];
+                        }
+                    }
                 }
-                r += 4;
-                while (r >= a.PH) { r -= a.PH; ++ci; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (dst[k] >= 0) patch[dst[k]] = v[k];
             }
         }
-        // ---- stage the weight slab: wl[(t*CK + r)*COTP + m]
-        {
+        // ---- stage the weight slab wl[(t*CK + r)*COTP + m]: lanes walk the contiguous run of the stored tensor
+        // (coalesced), wdec[] maps a run position to its LDS slot; loads are issued in independent batches.
+        if (!(a.dbg & 2)) {
             const int r0 = r_seg + c0;                        // reduction index of the chunk's first channel
             if (a.w_mode == 0) {
-                const int rr = lane & (CK - 1), msub = lane >> a.lck, mstep = 64 >> a.lck;
-                for (int m = msub + mstep * wave; m < 32 * MT; m += mstep * 4) {
-                    const bool ok = (m0 + m < a.M) && (rr < nch);
-                    const float *wp = a.w + ((int64_t)(a.m_base + m0 + m) * a.Rtot + r0 + rr) * a.KK;
-                    for (int t = 0; t < T; ++t)
-                        wl[(t * CK + rr) * a.COTP + m] = ok ? wp[a.tapmap[t]] : 0.f;
+                const int nE = CK * a.KK;
+                const float *wp0 = a.w + ((int64_t)(a.m_base + m0) * a.Rtot + r0) * a.KK;
+                for (int e = lane; e < nE; e += 64) {
+                    const int d = wdec[e];
+                    const bool use = d >= 0, rok = use && ((d >> 24) < nch);
+                    const int off = d & 0xFFFFFF;
+                    float v[8 * MT];
+#pragma unroll
+                    for (int k = 0; k < 8 * MT; ++k) {
+                        const int m = wave + 4 * k;
+                        v[k] = (rok && (m0 + m < a.M)) ? wp0[(int64_t)m * a.Rtot * a.KK + e] : 0.f;
+                    }
+                    if (use) {
+#pragma unroll
+                        for (int k = 0; k < 8 * MT; ++k) wl[off + wave + 4 * k] = v[k];
+                    }
                 }
             } else {
-                for (int mm = lane; mm < 32 * MT; mm += 64) {
-                    for (int rr = wave; rr < CK; rr += 4) {
-                        const bool ok = (m0 + mm < a.M) && (rr < nch);
-                        const float *wp = a.w + ((int64_t)(r0 + rr) * a.Mtot + a.m_base + m0 + mm) * a.KK;
-                        for (int t = 0; t < T; ++t)
-                            wl[(t * CK + rr) * a.COTP + mm] = ok ? wp[a.tapmap[t]] : 0.f;
+                const int nE = 32 * MT * a.KK;
+                const float *wp1 = a.w + ((int64_t)r0 * a.Mtot + a.m_base + m0) * a.KK;
+                constexpr int RK = (CK + 3) / 4;                // reduction rows per wave
+                for (int e0 = lane; e0 < nE; e0 += 256) {
+                    int d[4];
+                    float v[4][RK];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int e = e0 + 64 * jj;
+                        d[jj] = (e < nE) ? wdec[e] : -1;
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int e = e0 + 64 * jj;
+                        const bool mok = (d[jj] >= 0) && (m0 + (d[jj] >> 24) < a.M);
+#pragma unroll
+                        for (int k = 0; k < RK; ++k) {
+                            const int rr = wave + 4 * k;
+                            v[jj][k] = (mok && rr < nch) ? wp1[(int64_t)rr * a.Mtot * a.KK + e] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        if (d[jj] < 0) continue;
+#pragma unroll
+                        for (int k = 0; k < RK; ++k) {
+                            const int rr = wave + 4 * k;
+                            if (rr < CK) wl[(d[jj] & 0xFFFFFF) + rr * COTP] = v[jj][k];
+                        }
                     }
                 }
             }
         }
         __syncthreads();
-        // ---- MFMA over (channel pair, tap)
-        for (int cp = 0; cp < (CK >> 1); ++cp) {
-            for (int ta = 0; ta < a.TA; ++ta) {
-                for (int tb = 0; tb < a.TB; ++tb) {
-                    const int t = ta * a.TB + tb;
-                    const int toff = (a.IS == 2) ? ((tb & 1) * a.PWH + (tb >> 1)) : tb;
-                    const int po = cp * 2 * a.PS + ta * a.RS + toff;
-                    const int wo = (t * CK + cp * 2 + kh) * a.COTP + nl;
-                    float af[MT], bf[NT];
+        // ---- MFMA: per tap, all CKH channel pairs; the next tap's fragments are fetched before this tap's MFMAs
+        if (!(a.dbg & 4)) {
+            float af[2][CKH][MT], bf[2][CKH][NT];
+            auto load = [&](auto bufc, int t) {
+                constexpr int buf = decltype(bufc)::value;
+                const int tb_off = tapB[t];
+                const int wo = (t * CK + kh) * COTP + nl;
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) af[m] = wl[wo + m * 32];
+                for (int cp = 0; cp < CKH; ++cp) {
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) bf[i] = patch[boff[i] + po];
+                    for (int m = 0; m < MT; ++m) af[buf][cp][m] = wl[wo + cp * 2 * COTP + m * 32];
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) bf[buf][cp][i] = patch[boff[i] + tb_off + cp * 2 * PS];
+                }
+            };
+            auto mma = [&](auto bufc) {
+                constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+                for (int cp = 0; cp < CKH; ++cp)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int i = 0; i < NT; ++i)
-                            acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[i], acc[m][i], 0, 0, 0);
+                            acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][cp][m], bf[buf][cp][i], acc[m][i], 0, 0, 0);
+            };
+            using B0 = std::integral_constant<int, 0>;
+            using B1 = std::integral_constant<int, 1>;
+            load(B0{}, 0);
+            for (int t = 0; t < T; t += 2) {
+                if (t + 1 < T) load(B1{}, t + 1);
+                mma(B0{});
+                if (t + 1 < T) {
+                    if (t + 2 < T) load(B0{}, t + 2);
+                    mma(B1{});
                 }
             }
         }
@@ -164,8 +254,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int oy = oy0 + opy[i], ox = ox0 + opx[i];
-        const int Y = oy * a.OS + a.py, X = ox * a.OS + a.px;
-        const bool pok = (oy < a.OHc) && (ox < a.OWc) && (Y < a.OH) && (X < a.OW);
+        const int Y = oy * a.OS + c.py, X = ox * a.OS + c.px;
+        const bool pok = (oy < c.OHc) && (ox < c.OWc) && (Y < a.OH) && (X < a.OW);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -252,57 +342,95 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         const int tY = rem / a.tilesX, tX = rem - tY * a.tilesX;
         const int gy0 = tY * a.BH, gx0 = tX * WG_BW;
         __syncthreads();
-        // ---- stage Q patch
+        // ---- stage Q patch (units of (row, 64-column pass); 8 independent loads per batch)
         {
             const int qy0 = gy0 * a.S - a.pad, qx0 = gx0 * a.S - a.pad;
             const float *src = a.Q + ((int64_t)n * a.QCtot + a.q_base + c0) * a.QH * a.QW;
-            int ci = 0, r = wave;
-            while (r >= a.PHq) { r -= a.PHq; ++ci; }
-            while (ci < a.CK) {
-                const int iy = qy0 + r;
-                const bool rowok = (ci < nch) && (iy >= 0) && (iy < a.QH);
-                const float *rp = src + ((int64_t)ci * a.QH + iy) * a.QW;
-                float *dp = qp + ci * a.PS + r * a.RS;
-                for (int c = lane; c < a.PWq; c += 64) {
-                    const int ix = qx0 + c;
-                    const float v = (rowok && ix >= 0 && ix < a.QW) ? rp[ix] : 0.f;
-                    const int pos = (a.S == 2) ? ((c & 1) * a.PWH + (c >> 1)) : c;
-                    dp[pos] = v;
+            const int lnp = (a.PWq > 64) ? 1 : 0, units = (a.CK * a.PHq) << lnp;
+            for (int ub = wave; ub < units; ub += 32) {
+                float v[8];
+                int dst[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int u = ub + 4 * k;
+                    v[k] = 0.f;
+                    dst[k] = -1;
+                    if (u < units) {
+                        const int row = u >> lnp, cc = lane + ((u & lnp) << 6);
+                        const int ci = row / a.PHq, r = row - ci * a.PHq;
+                        if (cc < a.PWq) {
+                            const int iy = qy0 + r, ix = qx0 + cc;
+                            dst[k] = ci * a.PS + r * a.RS + ((a.S == 2) ? ((cc & 1) * a.PWH + (cc >> 1)) : cc);
+                            if (ci < nch && iy >= 0 && iy < a.QH && ix >= 0 && ix < a.QW)
+                                v[k] = src[((int64_t)ci * a.QH + iy) * a.QW + ix];
+                        }
+                    }
                 }
-                r += 4;
-                while (r >= a.PHq) { r -= a.PHq; ++ci; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (dst[k] >= 0) qp[dst[k]] = v[k];
             }
         }
-        // ---- stage P tile transposed: pl[pixel][m]; half-wave = one row of 32 pixels
+        // ---- stage P tile transposed: pl[pixel][m]; half-wave = one row of 32 pixels; 8 loads per batch
         {
             const int npairs = a.BH >> 1;          // row pairs per channel
             const int px = lane & 31, prow = lane >> 5;
-            for (int idx = wave; idx < 32 * MT * npairs; idx += 4) {
-                const int m = idx >> a.lnp, rp = idx - (m << a.lnp);
-                const int py = rp * 2 + prow;
-                const int gy = gy0 + py, gx = gx0 + px;
-                float v = 0.f;
-                if (m0 + m < a.M && gy < a.GH && gx < a.GW)
-                    v = a.P[(((int64_t)n * a.PCtot + a.m_base + m0 + m) * a.GH + gy) * a.GW + gx];
-                pl[(py * WG_BW + px) * a.COTP + m] = v;
+            const int total = 32 * MT * npairs;
+            for (int ib = wave; ib < total; ib += 32) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int idx = ib + 4 * k;
+                    const int m = idx >> a.lnp, rp = idx - (m << a.lnp);
+                    const int gy = gy0 + rp * 2 + prow, gx = gx0 + px;
+                    v[k] = 0.f;
+                    if (idx < total && m0 + m < a.M && gy < a.GH && gx < a.GW)
+                        v[k] = a.P[(((int64_t)n * a.PCtot + a.m_base + m0 + m) * a.GH + gy) * a.GW + gx];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int idx = ib + 4 * k;
+                    const int m = idx >> a.lnp, rp = idx - (m << a.lnp);
+                    if (idx < total) pl[((rp * 2 + prow) * WG_BW + px) * a.COTP + m] = v[k];
+                }
             }
         }
         __syncthreads();
-        // ---- MFMA over pixel pairs
-        for (int py = 0; py < a.BH; ++py) {
-            for (int px = 0; px < WG_BW; px += 2) {
-                const int p = py * WG_BW + px + kh;
-                const int qo = (py * a.S) * a.RS + px + kh;       // column part: pixel x (+tap offset in loff)
-                float af[MT], bf[NTW];
+        // ---- MFMA over pixel pairs: groups of 4 steps, the next group's fragments are fetched first
+        {
+            float af[2][4][MT], bf[2][4][NTW];
+            auto load = [&](auto bufc, int py, int px0) {
+                constexpr int buf = decltype(bufc)::value;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) af[m] = pl[p * a.COTP + m * 32 + nl];
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int px = px0 + 2 * s4 + kh;
+                    const int p = py * WG_BW + px;
+                    const int qo = (py * a.S) * a.RS + px;
 #pragma unroll
-                for (int u = 0; u < NTW; ++u) bf[u] = qp[loff[u] + qo];
+                    for (int m = 0; m < MT; ++m) af[buf][s4][m] = pl[p * a.COTP + m * 32 + nl];
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                    for (int u = 0; u < NTW; ++u) bf[buf][s4][u] = qp[loff[u] + qo];
+                }
+            };
+            auto mma = [&](auto bufc) {
+                constexpr int buf = decltype(bufc)::value;
 #pragma unroll
-                    for (int u = 0; u < NTW; ++u)
-                        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[u], acc[m][u], 0, 0, 0);
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int u = 0; u < NTW; ++u)
+                            acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][s4][m], bf[buf][s4][u], acc[m][u], 0, 0, 0);
+            };
+            using B0 = std::integral_constant<int, 0>;
+            using B1 = std::integral_constant<int, 1>;
+            const int ngroups = a.BH * 4;          // 32 pixels per row = 16 steps = 4 groups of 4 steps
+            load(B0{}, 0, 0);
+            for (int gq = 0; gq < ngroups; gq += 2) {
+                load(B1{}, (gq + 1) >> 2, ((gq + 1) & 3) * 8);
+                mma(B0{});
+                if (gq + 2 < ngroups) load(B0{}, (gq + 2) >> 2, ((gq + 2) & 3) * 8);
+                mma(B1{});
             }
         }
     }
@@ -356,14 +484,14 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 struct TilePlan { int lsw, lsh, TGX, TGY, NT; };
 
 // pick the 32-pixel tile shape and the arrangement of a block's tiles that waste the fewest MFMA columns
-TilePlan plan_tiles(int OHc, int OWc, int NT) {
+TilePlan plan_tiles(int OHc, int OWc, int NT, int maxBW = 64) {
     TilePlan best{5, 0, 1, 4 * NT, NT};
     double best_cost = 1e30;
     for (int lsw = 5; lsw >= 0; --lsw) {
         const int lsh = 5 - lsw, SW = 1 << lsw, SH = 1 << lsh;
         for (int TGX = 1; TGX <= 4 * NT; TGX *= 2) {
             const int TGY = 4 * NT / TGX, BW = TGX * SW, BH = TGY * SH;
-            if (BW > 64) continue;
+            if (BW > maxBW) continue;
             const double cov = (double)cdiv(OWc, BW) * BW * cdiv(OHc, BH) * BH;
             // small preference for wide tiles (coalesced stores) and compact patches
             const double cost = cov * (1.0 + 0.02 * lsh) + 1e-3 * (BW + BH);
@@ -375,84 +503,105 @@ TilePlan plan_tiles(int OHc, int OWc, int NT) {
 
 struct ClassSpec { int OS, py, px, IS, by, bx, TA, TB, OHc, OWc; int tapmap[49]; };
 
-// Fill the tiling fields of `a` for one class; returns the split-K factor (>= 1) or a negative error.
-int plan_gather(GatherArgs &a, const ClassSpec &cs) {
-    a.OS = cs.OS; a.py = cs.py; a.px = cs.px; a.IS = cs.IS; a.by = cs.by; a.bx = cs.bx;
-    a.TA = cs.TA; a.TB = cs.TB; a.OHc = cs.OHc; a.OWc = cs.OWc;
-    const int T = cs.TA * cs.TB;
-    if (T < 1 || T > 49 || cs.OHc <= 0 || cs.OWc <= 0) return DVF_ERR_INVALID_ARG;
-    for (int t = 0; t < T; ++t) a.tapmap[t] = cs.tapmap[t];
+struct GatherPlan { int MT, NT, CKH; size_t lds; dim3 grid; };
+
+// Fill the tiling fields of `a` for the classes of one op (they share one launch).  Returns 0 or an error.
+int plan_gather(GatherArgs &a, const ClassSpec *cls, int ncls, GatherPlan &pl) {
+    if (ncls < 1 || ncls > 4) return DVF_ERR_INVALID_ARG;
+    a.ncls = ncls; a.OS = cls[0].OS; a.IS = cls[0].IS;
+    int Tmax = 0, TAmax = 0, TBmax = 0, OHc = 0, OWc = 0, tap0 = 0;
+    for (int i = 0; i < ncls; ++i) {
+        const ClassSpec &c = cls[i];
+        const int T = c.TA * c.TB;
+        if (T < 1 || c.OHc <= 0 || c.OWc <= 0 || tap0 + T > 52) return DVF_ERR_INVALID_ARG;
+        a.cls[i] = ClassDev{c.py, c.px, c.by, c.bx, c.TA, c.TB, c.OHc, c.OWc, tap0};
+        for (int t = 0; t < T; ++t) a.tapmap[tap0 + t] = c.tapmap[t];
+        tap0 += T;
+        Tmax = T > Tmax ? T : Tmax; TAmax = c.TA > TAmax ? c.TA : TAmax; TBmax = c.TB > TBmax ? c.TB : TBmax;
+        OHc = c.OHc > OHc ? c.OHc : OHc; OWc = c.OWc > OWc ? c.OWc : OWc;
+    }
+    // Tile choice: measured on MI355X, large block tiles + split-K beat small tiles without it (the per-chunk
+    // staging cost is per block, so 4x smaller tiles stage 4x more per MFMA).
+    const int maxBW = ((64 - 1) * cls[0].IS + TBmax > 128) ? 32 : 64;
     const int MT = a.M > 32 ? 2 : 1;
-    const int64_t npix = (int64_t)cs.OHc * cs.OWc;
-    const int NT = (npix * a.N >= 4096) ? 2 : 1;
-    const TilePlan tp = plan_tiles(cs.OHc, cs.OWc, NT);
+    int NT = 2;
+    TilePlan tp = plan_tiles(OHc, OWc, NT, maxBW);
+    int64_t nblk = (int64_t)cdiv(OWc, tp.TGX << tp.lsw) * cdiv(OHc, tp.TGY << tp.lsh) * cdiv(a.M, 32 * MT) * a.N * ncls;
+    if (nblk < 768) {
+        NT = 1;
+        tp = plan_tiles(OHc, OWc, NT, maxBW);
+        nblk = (int64_t)cdiv(OWc, tp.TGX << tp.lsw) * cdiv(OHc, tp.TGY << tp.lsh) * cdiv(a.M, 32 * MT) * a.N * ncls;
+    }
+    const int mtiles = cdiv(a.M, 32 * MT);
     a.lsw = tp.lsw; a.lsh = tp.lsh; a.TGX = tp.TGX;
     a.BW = tp.TGX << tp.lsw; a.BH = tp.TGY << tp.lsh;
-    a.tilesX = cdiv(cs.OWc, a.BW);
-    a.tilesY = cdiv(cs.OHc, a.BH);
-    a.PH = (a.BH - 1) * a.IS + a.TA;
-    a.PW = (a.BW - 1) * a.IS + a.TB;
-    a.PWH = (a.PW + 1) / 2;
-    a.RS = (a.IS == 2) ? 2 * a.PWH : a.PW;
-    a.PS = a.PH * a.RS;
-    a.COTP = 32 * MT + 1;
+    if ((a.BW - 1) * a.IS + TBmax > 128) return DVF_ERR_UNSUPPORTED;   // patch rows are staged in <= 2 passes of 64
+    a.tilesX = cdiv(OWc, a.BW);
+    a.tilesY = cdiv(OHc, a.BH);
+    const int PH = (a.BH - 1) * a.IS + TAmax, PW = (a.BW - 1) * a.IS + TBmax, PWH = (PW + 1) / 2;
+    a.PSmax = PH * ((a.IS == 2) ? 2 * PWH : PW);
+    a.Tmax = Tmax;
+    const int COTP = 32 * MT + 1;
     int maxc = 0;
     for (int s = 0; s < a.nseg; ++s) maxc = a.segC[s] > maxc ? a.segC[s] : maxc;
-    // largest power-of-two chunk whose LDS footprint stays <= 40 KiB (3+ blocks per CU)
+    // largest chunk (2,4,8,16 channels) whose LDS footprint stays <= 40 KiB (3+ blocks per CU)
+    auto lds_bytes = [&](int CK) {
+        const int WD = (a.w_mode == 0 ? CK : 32 * MT) * a.KK;
+        return ((size_t)CK * a.PSmax + (size_t)Tmax * CK * COTP + WD + Tmax + 64) * 4;
+    };
     int CK = 16;
-    while (CK > 2 && ((int64_t)CK * a.PS + (int64_t)T * CK * a.COTP) * 4 > 40 * 1024) CK >>= 1;
+    while (CK > 2 && lds_bytes(CK) > 40 * 1024) CK >>= 1;
     while (CK > 2 && CK / 2 >= maxc) CK >>= 1;
-    a.CK = CK; a.lck = ilog2(CK);
-    if (((int64_t)CK * a.PS + (int64_t)T * CK * a.COTP) * 4 > 64 * 1024) return DVF_ERR_UNSUPPORTED;
+    if (lds_bytes(CK) > 64 * 1024) return DVF_ERR_UNSUPPORTED;
+    a.WD = (a.w_mode == 0 ? CK : 32 * MT) * a.KK;
     a.NCH = 0;
     for (int s = 0; s < a.nseg; ++s) a.NCH += cdiv(a.segC[s], CK);
-    const int64_t nblk = (int64_t)a.tilesX * a.tilesY * cdiv(a.M, 32 * MT) * a.N;
     int KS = 1;
-    if (nblk < 512) KS = (int)((768 + nblk - 1) / nblk);
+    if (nblk < 384) KS = (int)((512 + nblk - 1) / nblk);
     if (KS > a.NCH) KS = a.NCH;
     if (KS < 1) KS = 1;
-    if ((int64_t)a.N * KS > 65535) return DVF_ERR_UNSUPPORTED;
+    if ((int64_t)a.N * KS * ncls > 65535) return DVF_ERR_UNSUPPORTED;
     a.KS = KS;
-    return KS;
+    if (const char *e = getenv("DVF_DBG")) a.dbg = atoi(e);     // ablation switches for tools/conv_bench.py only
+    pl.MT = MT; pl.NT = NT; pl.CKH = CK / 2; pl.lds = lds_bytes(CK);
+    pl.grid = dim3(a.tilesX * a.tilesY, mtiles, a.N * KS * ncls);
+    return DVF_OK;
 }
 
-int run_gather(const GatherArgs &a, hipStream_t st) {
-    const int MT = a.M > 32 ? 2 : 1;
-    const int NT = ((a.BW >> a.lsw) * (a.BH >> a.lsh)) / 4;
-    const int T = a.TA * a.TB;
-    const size_t lds = ((size_t)a.CK * a.PS + (size_t)T * a.CK * a.COTP) * 4;
-    const dim3 grid(a.tilesX * a.tilesY, cdiv(a.M, 32 * MT), a.N * a.KS);
-    if (MT == 2 && NT == 2) conv_gather_kernel<2, 2><<<grid, 256, lds, st>>>(a);
-    else if (MT == 2) conv_gather_kernel<2, 1><<<grid, 256, lds, st>>>(a);
-    else if (NT == 2) conv_gather_kernel<1, 2><<<grid, 256, lds, st>>>(a);
-    else conv_gather_kernel<1, 1><<<grid, 256, lds, st>>>(a);
+template <int MT, int NT>
+int launch_gather_ck(const GatherArgs &a, const GatherPlan &pl, hipStream_t st) {
+    switch (pl.CKH) {
+        case 1: conv_gather_kernel<MT, NT, 1><<<pl.grid, 256, pl.lds, st>>>(a); break;
+        case 2: conv_gather_kernel<MT, NT, 2><<<pl.grid, 256, pl.lds, st>>>(a); break;
+        case 4: conv_gather_kernel<MT, NT, 4><<<pl.grid, 256, pl.lds, st>>>(a); break;
+        case 8: conv_gather_kernel<MT, NT, 8><<<pl.grid, 256, pl.lds, st>>>(a); break;
+        default: return DVF_ERR_UNSUPPORTED;
+    }
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }
 
-// Run the classes of one op.  If any class needs split-K every class accumulates with atomics into a zeroed
-// output and bias + activation are applied by one finishing pass; otherwise they are fused in the epilogue.
+// Run the classes of one op in ONE launch.  With split-K (or classes that do not cover every output pixel) the
+// blocks accumulate with atomics into a zeroed output and bias + activation are applied by one finishing pass;
+// otherwise they are fused in the epilogue.
 int run_classes(const GatherArgs &base, const ClassSpec *cls, int ncls, bool covers_all, hipStream_t st) {
-    GatherArgs planned[4];
-    if (ncls < 1 || ncls > 4) return DVF_ERR_INVALID_ARG;
-    bool split = !covers_all;
-    for (int i = 0; i < ncls; ++i) {
-        planned[i] = base;
-        const int ks = plan_gather(planned[i], cls[i]);
-        if (ks < 0) return ks;
-        if (ks > 1) split = true;
-    }
-    const int64_t HW = (int64_t)base.OH * base.OW, total = (int64_t)base.N * base.M * HW;
-    if (split && hipMemsetAsync(base.out, 0, sizeof(float) * total, st) != hipSuccess) return DVF_ERR_LAUNCH;
-    for (int i = 0; i < ncls; ++i) {
-        planned[i].atomic_out = split ? 1 : 0;
-        const int rc = run_gather(planned[i], st);
-        if (rc) return rc;
-    }
-    if (split && (base.bias || base.act != DVF_ACT_NONE)) {
+    GatherArgs a = base;
+    GatherPlan pl;
+    int rc = plan_gather(a, cls, ncls, pl);
+    if (rc) return rc;
+    const bool split = !covers_all || a.KS > 1;
+    const int64_t HW = (int64_t)a.OH * a.OW, total = (int64_t)a.N * a.M * HW;
+    if (split && hipMemsetAsync(a.out, 0, sizeof(float) * total, st) != hipSuccess) return DVF_ERR_LAUNCH;
+    a.atomic_out = split ? 1 : 0;
+    if (pl.MT == 2 && pl.NT == 2) rc = launch_gather_ck<2, 2>(a, pl, st);
+    else if (pl.MT == 2) rc = launch_gather_ck<2, 1>(a, pl, st);
+    else if (pl.NT == 2) rc = launch_gather_ck<1, 2>(a, pl, st);
+    else rc = launch_gather_ck<1, 1>(a, pl, st);
+    if (rc) return rc;
+    if (split && (a.bias || a.act != DVF_ACT_NONE)) {
         const int64_t nb = (total + 255) / 256;
-        bias_act_kernel<<<(int)(nb > 2048 ? 2048 : nb), 256, 0, st>>>(base.out, base.bias, base.M, HW, total, base.act,
-                                                                     base.alpha, base.beta);
+        bias_act_kernel<<<(int)(nb > 2048 ? 2048 : nb), 256, 0, st>>>(a.out, a.bias, a.M, HW, total, a.act, a.alpha,
+                                                                     a.beta);
         DVF_LAUNCH_CHECK();
     }
     return DVF_OK;

@@ -47,7 +47,8 @@ class ConvFn(torch.autograd.Function):
         # algorithmic MACs of this layer: kept pixels x taps actually contributing
         taps = k * k / (stride * stride) if transposed else k * k
         ctx.macs = float(N) * cout * oh * ow * cin * taps
-        with L.timed("conv_fwd", 2 * ctx.macs):
+        ctx.tag = f"{'T' if transposed else 'C'}{k}x{k}s{stride} {cin}->{cout} in{H}x{W} out{oh}x{ow} N{N}"
+        with L.timed("conv_fwd", 2 * ctx.macs, tag=ctx.tag):
             L.check(L.lib().dvf_conv2d_fwd(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc), len(segc),
                                            L.dev(weight, "weight"), L.dev(bias, "bias"), L.dev(out), L.stream()),
                     "dvf_conv2d_fwd")
@@ -78,14 +79,14 @@ class ConvFn(torch.autograd.Function):
         gins = [torch.empty_like(x) if need else None for x, need in zip(inputs, need_in)]
         if any(need_in):
             frac = sum(c for c, need in zip(segc, need_in) if need) / float(sum(segc))
-            with L.timed("conv_dgrad", 2 * ctx.macs * frac):
+            with L.timed("conv_dgrad", 2 * ctx.macs * frac, tag=ctx.tag):
                 L.check(lib.dvf_conv2d_dgrad(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins),
                                              L.int_array(segc), len(segc), L.stream()), "dvf_conv2d_dgrad")
         dw = None
         if need_w:
             arena = ctx.wparam is not None
             dw = ctx.wparam._dvf_grad if arena else torch.empty_like(weight)
-            with L.timed("conv_wgrad", 2 * ctx.macs):
+            with L.timed("conv_wgrad", 2 * ctx.macs, tag=ctx.tag):
                 L.check(lib.dvf_conv2d_wgrad(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
                                              L.dev(dpre), L.dev(dw), 1 if arena else 0, L.stream()), "dvf_conv2d_wgrad")
             if arena:

@@ -135,15 +135,24 @@ class KernelTimer:
         ev.record(torch.cuda.current_stream())
         return ev
 
-    def stop(self, kind, start_ev, flops=0.0, nbytes=0.0):
+    def stop(self, kind, start_ev, flops=0.0, nbytes=0.0, tag=""):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
-        self.records.append((kind, start_ev, ev, float(flops), float(nbytes)))
+        self.records.append((kind, start_ev, ev, float(flops), float(nbytes), tag))
+
+    def table(self):
+        """Per-call rows (kind, tag, ms, TFLOP/s, GB/s), slowest first."""
+        torch.cuda.synchronize()
+        rows = []
+        for kind, a, b, fl, by, tag in self.records:
+            ms = a.elapsed_time(b)
+            rows.append((ms, kind, tag, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0))
+        return sorted(rows, reverse=True)
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind, a, b, fl, by in self.records:
+        for kind, a, b, fl, by, _tag in self.records:
             d = out.setdefault(kind, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["calls"] += 1
             d["ms"] += a.elapsed_time(b)
@@ -155,16 +164,16 @@ class KernelTimer:
 TIMER = None    # set to a KernelTimer() to record
 
 
-def timed(kind, flops=0.0, nbytes=0.0):
+def timed(kind, flops=0.0, nbytes=0.0, tag=""):
     """Context manager: times the enclosed launches when TIMER is active."""
-    return _Timed(kind, flops, nbytes)
+    return _Timed(kind, flops, nbytes, tag)
 
 
 class _Timed:
-    __slots__ = ("kind", "flops", "nbytes", "ev")
+    __slots__ = ("kind", "flops", "nbytes", "ev", "tag")
 
-    def __init__(self, kind, flops, nbytes):
-        self.kind, self.flops, self.nbytes, self.ev = kind, flops, nbytes, None
+    def __init__(self, kind, flops, nbytes, tag):
+        self.kind, self.flops, self.nbytes, self.ev, self.tag = kind, flops, nbytes, None, tag
 
     def __enter__(self):
         if TIMER is not None:
@@ -173,5 +182,5 @@ class _Timed:
 
     def __exit__(self, *exc):
         if self.ev is not None and TIMER is not None:
-            TIMER.stop(self.kind, self.ev, self.flops, self.nbytes)
+            TIMER.stop(self.kind, self.ev, self.flops, self.nbytes, self.tag)
         return False

@@ -178,6 +178,6 @@ def test_graphed_step_matches_eager():
     assert max(abs(a - b) / abs(a) for a, b in zip(l0, l1)) < 1e-4
     # Parameters: float atomics make gradients differ by ~1e-7 relative from run to run (eager vs eager too), and
     # Adam's first steps move an element by lr * g/(|g| + eps), which is O(lr) sensitive where |g| ~ eps = 1e-8.
-    # So: every element within the hard bound 2*lr per step, and the parameter vector as a whole equal to 1e-3.
+    # So: every element within the hard bound 2*lr per step, and the parameter vector as a whole equal to 3e-3.
     assert float((p1 - p0).abs().max()) <= 2 * 1e-3 * 4
-    assert float((p1 - p0).norm() / p0.norm()) < 1e-3
+    assert float((p1 - p0).norm() / p0.norm()) < 3e-3       # two eager runs differ by ~1e-3 already
