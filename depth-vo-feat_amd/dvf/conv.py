@@ -165,6 +165,45 @@ class SpatialMeanFn(torch.autograd.Function):
         return gin, None
 
 
+class DepthwiseUp2xFn(torch.autograd.Function):
+    """skip + ConvTranspose2d(C, C, 4, stride=2, padding=1, groups=C)(x): one top-down step of FeatExtractor
+    (reference feat_extractor.py:72-82)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, skip):
+        ctx.wparam = weight if getattr(weight, "_dvf_grad", None) is not None else None
+        ctx.bparam = bias if getattr(bias, "_dvf_grad", None) is not None else None
+        x, weight, bias, skip = _c(x), _c(weight), _c(bias), _c(skip)
+        N, C, H, W = x.shape
+        if tuple(skip.shape) != (N, C, 2 * H, 2 * W) or tuple(weight.shape) != (C, 1, 4, 4):
+            raise ValueError(f"shape mismatch: x {tuple(x.shape)} weight {tuple(weight.shape)} skip {tuple(skip.shape)}")
+        out = torch.empty_like(skip)
+        L.check(L.lib().dvf_dwconvt4x4s2_fwd(L.dev(x, "input"), L.dev(weight, "weight"), L.dev(bias, "bias"),
+                                             L.dev(skip, "skip"), L.dev(out), N, C, H, W, L.stream()), "dvf_dwconvt4x4s2_fwd")
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, weight = ctx.saved_tensors
+        N, C, H, W = x.shape
+        gout = _c(gout)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        db = torch.empty(C, device=x.device) if (dw is not None and ctx.needs_input_grad[2]) else None
+        L.check(L.lib().dvf_dwconvt4x4s2_bwd(L.dev(x), L.dev(weight), L.dev(gout, "grad_out"), L.dev(dx), L.dev(dw), L.dev(db),
+                                             N, C, H, W, L.stream()), "dvf_dwconvt4x4s2_bwd")
+        if dw is not None and ctx.wparam is not None:
+            ctx.wparam._dvf_grad.add_(dw)
+            ctx.wparam._dvf_owner.grad_ready(ctx.wparam)
+            dw = None
+        if db is not None and ctx.bparam is not None:
+            ctx.bparam._dvf_grad.add_(db)
+            ctx.bparam._dvf_owner.grad_ready(ctx.bparam)
+            db = None
+        return dx, dw, db, (gout if ctx.needs_input_grad[3] else None)
+
+
 def reciprocal(x, eps=0.0):
     return RecipFn.apply(x, float(eps))
 
@@ -231,6 +270,20 @@ class FusedConvTranspose2d(FusedConv2d):
     transposed = True
 
 
+class DepthwiseUp2x(nn.Module):
+    """nn.ConvTranspose2d(C, C, kernel_size=4, padding=1, stride=2, groups=C) with the following residual add fused;
+    parameter layout [C, 1, 4, 4] as torch's."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.channels = channels
+        self.weight = nn.Parameter(torch.empty(channels, 1, 4, 4).uniform_(-0.25, 0.25))
+        self.bias = nn.Parameter(torch.empty(channels).uniform_(-0.25, 0.25))
+
+    def forward(self, x, skip):
+        return DepthwiseUp2xFn.apply(x, self.weight, self.bias, skip)
+
+
 class FusedAct(nn.Module):
     """Index placeholder: keeps the reference's nn.Sequential numbering (conv1.0 / conv1.2 ...) while the
     activation itself runs in the epilogue of the preceding convolution kernel."""
@@ -243,6 +296,6 @@ def xavier_init_(module):
     """init_weights() of the reference nets: xavier_uniform_ on every conv weight, zero bias
     (DispNetS.py:81-86, PoseExpNet_sfm.py:51-56, feat_extractor.py:85-90)."""
     for m in module.modules():
-        if isinstance(m, FusedConv2d):
+        if isinstance(m, (FusedConv2d, DepthwiseUp2x)):
             nn.init.xavier_uniform_(m.weight)
             nn.init.zeros_(m.bias)

@@ -59,6 +59,8 @@ SIGNATURES = {
     "dvf_spatial_mean_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_f, c_fp]),
     "dvf_spatial_mean_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_f, c_fp]),
     "dvf_area_downsample": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_fp]),
+    "dvf_dwconvt4x4s2_fwd": (c_i, [c_fp] * 5 + [c_i] * 4 + [c_fp]),
+    "dvf_dwconvt4x4s2_bwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_fp]),
     "dvf_bce_ones_fwd": (c_i, [c_fp, c_fp, c_fp, c_i64, c_i, c_fp]),
     "dvf_bce_ones_bwd": (c_i, [c_fp, c_fp, c_fp, c_i64, c_fp]),
     "dvf_adam_step": (c_i, [c_fp] * 4 + [c_i64, c_fp, c_i] + [c_f] * 5 + [c_fp]),

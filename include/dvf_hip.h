@@ -142,6 +142,13 @@ int dvf_spatial_mean_fwd(const float *in, float *out, int planes, int HW, float 
 int dvf_spatial_mean_bwd(const float *gout, float *gin, int planes, int HW, float scale, void *stream);
 /* F.interpolate(mode='area') = adaptive average pooling (loss_functions_sfm.py:18-19) */
 int dvf_area_downsample(const float *in, float *out, int planes, int H, int W, int OH, int OW, void *stream);
+/* Depthwise nn.ConvTranspose2d(C, C, kernel_size=4, stride=2, padding=1, groups=C) of FeatExtractor's top-down path
+ * (feat_extractor.py:38-41) with the residual add of :72-82 fused: out = skip + convT(x) + bias.  w [C,1,4,4];
+ * x [N,C,H,W]; skip/out [N,C,2H,2W]; skip, bias may be NULL.  Backward: dx, dw (+db) from dy (d skip = dy). */
+int dvf_dwconvt4x4s2_fwd(const float *x, const float *w, const float *bias, const float *skip, float *out, int N, int C,
+                         int H, int W, void *stream);
+int dvf_dwconvt4x4s2_bwd(const float *x, const float *w, const float *dy, float *dx, float *dw, float *db, int N, int C,
+                         int H, int W, void *stream);
 /* explainability_loss of one scale (loss_functions_sfm.py:49-56): loss_out[0] (+)= -mean(max(log mask, -100));
  * partials: workspace of >= 1024 floats.  Backward: g_mask = -grad_loss / (n * mask). */
 int dvf_bce_ones_fwd(const float *mask, float *loss_out, float *partials, int64_t n, int accumulate, void *stream);

@@ -181,3 +181,43 @@ def test_graphed_step_matches_eager():
     # So: every element within the hard bound 2*lr per step, and the parameter vector as a whole equal to 3e-3.
     assert float((p1 - p0).abs().max()) <= 2 * 1e-3 * 4
     assert float((p1 - p0).norm() / p0.norm()) < 3e-3       # two eager runs differ by ~1e-3 already
+
+
+def test_featnet_golden():
+    import feat_extractor
+    g = load_golden("net_featnet")
+    net = _load(feat_extractor.FeatExtractor(), onets.fill_params(onets.featnet_layers(), seed=3))
+    out = net(t(g["x"], DEV))
+    assert rel_err(out, g["out"]) < TOL
+    (out * t(g["wt"], DEV)).sum().backward()
+    _check_digest(g, {k: p.grad for k, p in net.named_parameters()})
+
+
+def test_step_unsupervise_feat_golden():
+    """cfg 3 family: image + 0.1 * feature reconstruction (32-channel maps, gradients into all three feature
+    maps through the scatter-add backward) + 10 * smooth, three optimizer groups, two iterations."""
+    import DispNetS
+    import PoseExpNet
+    import feat_extractor
+    from dvf.engine import FlatAdam
+    from dvf.steps import unsupervise_losses
+    g = load_golden("step_unsup_feat")
+    b, h, w = int(g["b"]), int(g["h"]), int(g["w"])
+    batch = _batch(b, h, w)
+    disp = _load(DispNetS.DispNetS(), onets.fill_params(onets.dispnet_layers(), seed=1))
+    pose = _load(PoseExpNet.PoseExpNet(output_exp=True), onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2))
+    feat = _load(feat_extractor.FeatExtractor(), onets.fill_params(onets.featnet_layers(), seed=3))
+    opt = FlatAdam(list(pose.parameters()) + list(disp.parameters()) + list(feat.parameters()), lr=1e-3, weight_decay=1e-8)
+    for it in range(2):
+        loss, terms = unsupervise_losses(disp, pose, batch, feat_extractor=feat)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            _check_digest(g, {k: p.grad for k, p in disp.named_parameters() if p.grad is not None}, "g_disp_")
+            _check_digest(g, {k: p.grad for k, p in pose.named_parameters() if p.grad is not None}, "g_pose_")
+        opt.step()
+        for k in ("img", "smooth", "feat", "total"):
+            assert rel_err(terms[k], g[f"{k}{it}"]) < TOL, k
+    _check_params(g, "disp", disp, 1e-3)
+    _check_params(g, "pose", pose, 1e-3)
+    _check_params(g, "feat", feat, 1e-3)
