@@ -46,6 +46,21 @@ struct GatherArgs {
     int tapmap[52];      // class c uses tapmap[cls[c].tap0 + t]: class tap -> tap index of the stored kernel
 };
 
+// Raw buffer descriptor over a whole tensor, built from wave-uniform values (readfirstlane keeps hipcc from
+// wrapping every load in a waterfall loop).  num_records is 2^31-16: the per-lane offset (voffset) of a valid element is
+// always below it, and an invalid element is requested at voffset 0x80000000, which the hardware range check turns
+// into a load of 0.0f -- exactly the zero padding the LDS images need.  The scalar offset (soffset) carries the
+// row base; it is added to the address but is not part of the range check.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tensor_rsrc(const void *p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, 0x7FFFFFF0, 0x00020000);
+}
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float alpha, float beta) {
     if (act == DVF_ACT_RELU) return fmaxf(v, 0.f);
     if (act == DVF_ACT_SIGMOID_AFFINE) return alpha * (1.f / (1.f + expf(-v))) + beta;
@@ -62,7 +77,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
     int *wdec = reinterpret_cast<int *>(wl + a.Tmax * CK * COTP);   // weight run element -> LDS offset
     int *tapB = wdec + a.WD;                               // class tap -> patch offset
     int *inv = tapB + a.Tmax;                              // stored tap -> class tap
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, kh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, nl = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: row/column bookkeeping stays scalar
     const int zc = blockIdx.z % a.ncls, zr = blockIdx.z / a.ncls;
     const int n = zr / a.KS, ks = zr - n * a.KS;
     const ClassDev c = a.cls[zc];
@@ -112,6 +128,17 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
             for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
 
     const int iy0 = oy0 * a.IS + c.by, ix0 = ox0 * a.IS + c.bx;
+    // lane-invariant column part of the patch staging: byte offset inside a row (or OOB) and LDS column (or -1)
+    const bool npass2 = PW > 64;
+    unsigned pcol_off[2];
+    int pcol_dst[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int cc = lane + 64 * ps, ix = ix0 + cc;
+        pcol_off[ps] = (cc < PW && ix >= 0 && ix < a.IW) ? ((unsigned)ix << 2) : OOB;
+        pcol_dst[ps] = (cc < PW) ? ((a.IS == 2) ? ((cc & 1) * PWH + (cc >> 1)) : cc) : -1;
+    }
+    const __amdgpu_buffer_rsrc_t rs_w = tensor_rsrc(a.w);
     const int g_begin = (int)(((int64_t)a.NCH * ks) / a.KS), g_end = (int)(((int64_t)a.NCH * (ks + 1)) / a.KS);
     int seg = 0, seg_first = 0, r_seg = 0;     // r_seg: index of the segment's first channel in the concat
     for (int g = g_begin; g < g_end; ++g) {
@@ -124,53 +151,60 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
         }
         const int c0 = (g - seg_first) * CK;                  // first channel of the chunk inside its segment
         const int nch = min(CK, a.segC[seg] - c0);            // valid channels in this chunk
-        const float *src = a.in[seg] + ((int64_t)n * a.segC[seg] + c0) * a.IH * a.IW;
         __syncthreads();                                      // previous chunk fully consumed (and tables visible)
-        // ---- stage the input patch.  Unit = (patch row, 64-column pass); each wave takes every 4th unit and
-        // issues 8 independent global loads before the 8 LDS stores (a load -> store -> load chain would expose
-        // the full memory latency once per row).
+        // ---- stage the input patch.  Row bookkeeping is scalar and incremental (no divisions); everything that
+        // depends on the lane (column offset, column validity, LDS column) was computed once before the chunk loop.
+        // 8 independent buffer loads are issued before the 8 LDS stores.
         if (!(a.dbg & 1)) {
-            const int lnp = (PW > 64) ? 1 : 0, units = (CK * PH) << lnp;
-            for (int ub = wave; ub < units; ub += 32) {
-                float v[8];
-                int dst[8];
+            const __amdgpu_buffer_rsrc_t rs_in = tensor_rsrc(a.in[seg]);
+            const unsigned cb = (unsigned)((n * a.segC[seg] + c0) * a.IH * a.IW) << 2;      // chunk base, bytes
+            int ci = 0, r = wave;                              // this wave's next row (ci, r); rows advance by 4
+            while (r >= PH) { r -= PH; ++ci; }
+            while (ci < CK) {
+                float v[8][2];
+                int dsts[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int u = ub + 4 * k;
-                    v[k] = 0.f;
-                    dst[k] = -1;
-                    if (u < units) {
-                        const int row = u >> lnp, cc = lane + ((u & lnp) << 6);
-                        const int ci = row / PH, r = row - ci * PH;
-                        if (cc < PW) {
-                            const int iy = iy0 + r, ix = ix0 + cc;
-                            dst[k] = ci * PS + r * RS + ((a.IS == 2) ? ((cc & 1) * PWH + (cc >> 1)) : cc);
-                            if (ci < nch && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
-                                v[k] = src[((int64_t)ci * a.IH + iy) * a.IW + ix];
-                        }
+                    dsts[k] = -1;
+                    if (ci < CK) {
+                        const int iy = iy0 + r;
+                        const bool rowok = (ci < nch) & (iy >= 0) & (iy < a.IH);
+                        const unsigned soff = cb + ((unsigned)((ci * a.IH + iy) * a.IW) << 2);
+                        dsts[k] = ci * PS + r * RS;
+                        v[k][0] = bload(rs_in, rowok ? pcol_off[0] : OOB, rowok ? soff : 0u);
+                        if (npass2) v[k][1] = bload(rs_in, rowok ? pcol_off[1] : OOB, rowok ? soff : 0u);
+                        r += 4;
+                        while (r >= PH) { r -= PH; ++ci; }
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (dst[k] >= 0) patch[dst[k]] = v[k];
+                for (int k = 0; k < 8; ++k) {
+                    if (dsts[k] >= 0) {
+                        if (pcol_dst[0] >= 0) patch[dsts[k] + pcol_dst[0]] = v[k][0];
+                        if (npass2 && pcol_dst[1] >= 0) patch[dsts[k] + pcol_dst[1]] = v[k][1];
+                    }
+                }
             }
         }
         // ---- stage the weight slab wl[(t*CK + r)*COTP + m]: lanes walk the contiguous run of the stored tensor
-        // (coalesced), wdec[] maps a run position to its LDS slot; loads are issued in independent batches.
+        // (coalesced), wdec[] maps a run position to its LDS slot; row bases are scalar 32-bit offsets.
         if (!(a.dbg & 2)) {
             const int r0 = r_seg + c0;                        // reduction index of the chunk's first channel
             if (a.w_mode == 0) {
                 const int nE = CK * a.KK;
-                const float *wp0 = a.w + ((int64_t)(a.m_base + m0) * a.Rtot + r0) * a.KK;
+                const unsigned wb = (unsigned)(((a.m_base + m0) * a.Rtot + r0) * a.KK) << 2;
+                const unsigned rowstep = (unsigned)(a.Rtot * a.KK) << 2;
                 for (int e = lane; e < nE; e += 64) {
                     const int d = wdec[e];
-                    const bool use = d >= 0, rok = use && ((d >> 24) < nch);
+                    const bool use = d >= 0;
+                    const unsigned voff = (use && ((d >> 24) < nch)) ? ((unsigned)e << 2) : OOB;
                     const int off = d & 0xFFFFFF;
                     float v[8 * MT];
 #pragma unroll
                     for (int k = 0; k < 8 * MT; ++k) {
                         const int m = wave + 4 * k;
-                        v[k] = (rok && (m0 + m < a.M)) ? wp0[(int64_t)m * a.Rtot * a.KK + e] : 0.f;
+                        const bool mok = m0 + m < a.M;
+                        v[k] = bload(rs_w, mok ? voff : OOB, mok ? wb + (unsigned)m * rowstep : 0u);
                     }
                     if (use) {
 #pragma unroll
@@ -179,7 +213,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
                 }
             } else {
                 const int nE = 32 * MT * a.KK;
-                const float *wp1 = a.w + ((int64_t)r0 * a.Mtot + a.m_base + m0) * a.KK;
+                const unsigned wb = (unsigned)((r0 * a.Mtot + a.m_base + m0) * a.KK) << 2;
+                const unsigned rowstep = (unsigned)(a.Mtot * a.KK) << 2;
                 constexpr int RK = (CK + 3) / 4;                // reduction rows per wave
                 for (int e0 = lane; e0 < nE; e0 += 256) {
                     int d[4];
@@ -192,11 +227,12 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         const int e = e0 + 64 * jj;
-                        const bool mok = (d[jj] >= 0) && (m0 + (d[jj] >> 24) < a.M);
+                        const unsigned voff = ((d[jj] >= 0) && (m0 + (d[jj] >> 24) < a.M)) ? ((unsigned)e << 2) : OOB;
 #pragma unroll
                         for (int k = 0; k < RK; ++k) {
                             const int rr = wave + 4 * k;
-                            v[jj][k] = (mok && rr < nch) ? wp1[(int64_t)rr * a.Mtot * a.KK + e] : 0.f;
+                            const bool rok = rr < nch;
+                            v[jj][k] = bload(rs_w, rok ? voff : OOB, rok ? wb + (unsigned)rr * rowstep : 0u);
                         }
                     }
 #pragma unroll
@@ -307,7 +343,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *qp = smem;                               // [CK][PHq][RS]
     float *pl = smem + a.CK * a.PS;                 // [BH*32 pixels][COTP]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 31, kh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, nl = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * (32 * MT);
     const int c0 = blockIdx.y * a.CK;
     const int nch = min(a.CK, a.Cq - c0);
@@ -563,6 +600,10 @@ int plan_gather(GatherArgs &a, const ClassSpec *cls, int ncls, GatherPlan &pl) {
     if ((int64_t)a.N * KS * ncls > 65535) return DVF_ERR_UNSUPPORTED;
     a.KS = KS;
     if (const char *e = getenv("DVF_DBG")) a.dbg = atoi(e);     // ablation switches for tools/conv_bench.py only
+    // the kernels address each tensor with 32-bit byte offsets
+    for (int s2 = 0; s2 < a.nseg; ++s2)
+        if ((int64_t)a.N * a.segC[s2] * a.IH * a.IW * 4 >= ((int64_t)1 << 31) - 16) return DVF_ERR_UNSUPPORTED;
+    if ((int64_t)a.Mtot * a.Rtot * a.KK * 4 >= ((int64_t)1 << 31) - 16) return DVF_ERR_UNSUPPORTED;
     pl.MT = MT; pl.NT = NT; pl.CKH = CK / 2; pl.lds = lds_bytes(CK);
     pl.grid = dim3(a.tilesX * a.tilesY, mtiles, a.N * KS * ncls);
     return DVF_OK;
