@@ -147,7 +147,10 @@ def test_step_train_sfm_golden():
 
 
 def test_graphed_step_matches_eager():
-    """The HIP-graph replay of a whole step produces the same losses and parameters as eager execution."""
+    """The HIP-graph replay of a whole step is equivalent to eager execution.  Two EAGER runs already differ (float
+    atomics in wgrad / split-K / pose partials change summation order, and Adam's first steps move an element by
+    lr*g/(|g|+eps), which is O(lr)-sensitive where |g| ~ eps), so the graph run is held to 3x the eager-vs-eager
+    spread, with every element inside the hard bound of 2*lr per step."""
     import DispNetS
     import PoseExpNet
     from dvf.engine import FlatAdam, GraphedStep
@@ -155,7 +158,7 @@ def test_graphed_step_matches_eager():
     b, h, w = 1, 64, 128
     batch = _batch(b, h, w)
     results = []
-    for graphed in (False, True):
+    for mode in ("eager", "eager", "graph"):
         disp = _load(DispNetS.DispNetS(), onets.fill_params(onets.dispnet_layers(), seed=1))
         pose = _load(PoseExpNet.PoseExpNet(output_exp=True), onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2))
         opt = FlatAdam(list(pose.parameters()) + list(disp.parameters()), lr=1e-3, weight_decay=1e-8)
@@ -167,20 +170,19 @@ def test_graphed_step_matches_eager():
             opt.step()
             return (terms["total"],)
 
-        if graphed:
+        if mode == "graph":
             runner = GraphedStep(step, [], warmup=2)       # 2 eager steps, then capture (enqueues nothing)
             losses = [float(runner()[0]) for _ in range(2)]  # replays = steps 3 and 4
         else:
             losses = [float(step()[0]) for _ in range(4)][2:]
         torch.cuda.synchronize()
         results.append((losses, opt.flat_p.clone()))
-    (l0, p0), (l1, p1) = results
-    assert max(abs(a - b) / abs(a) for a, b in zip(l0, l1)) < 1e-4
-    # Parameters: float atomics make gradients differ by ~1e-7 relative from run to run (eager vs eager too), and
-    # Adam's first steps move an element by lr * g/(|g| + eps), which is O(lr) sensitive where |g| ~ eps = 1e-8.
-    # So: every element within the hard bound 2*lr per step, and the parameter vector as a whole equal to 3e-3.
-    assert float((p1 - p0).abs().max()) <= 2 * 1e-3 * 4
-    assert float((p1 - p0).norm() / p0.norm()) < 3e-3       # two eager runs differ by ~1e-3 already
+    (l0, p0), (l1, p1), (l2, p2) = results
+    spread_l = max(abs(a - b) / abs(a) for a, b in zip(l0, l1))
+    spread_p = float((p1 - p0).norm() / p0.norm())
+    assert max(abs(a - b) / abs(a) for a, b in zip(l0, l2)) <= max(1e-4, 3 * spread_l)
+    assert float((p2 - p0).abs().max()) <= 2 * 1e-3 * 4
+    assert float((p2 - p0).norm() / p0.norm()) <= max(1e-3, 3 * spread_p)
 
 
 def test_featnet_golden():
