@@ -373,56 +373,75 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][u][r] = 0.f;
 
+    const __amdgpu_buffer_rsrc_t rs_q = tensor_rsrc(a.Q), rs_p = tensor_rsrc(a.P);
+    const bool qpass2 = a.PWq > 64;
+    int qcol_dst[2];                               // lane-invariant LDS column of the Q patch (or -1)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int cc = lane + 64 * ps;
+        qcol_dst[ps] = (cc < a.PWq) ? ((a.S == 2) ? ((cc & 1) * a.PWH + (cc >> 1)) : cc) : -1;
+    }
     const int ntiles = a.N * a.tilesX * a.tilesY;
     for (int tile = blockIdx.z; tile < ntiles; tile += a.PSPLIT) {
         const int n = tile / (a.tilesX * a.tilesY), rem = tile - n * (a.tilesX * a.tilesY);
         const int tY = rem / a.tilesX, tX = rem - tY * a.tilesX;
         const int gy0 = tY * a.BH, gx0 = tX * WG_BW;
         __syncthreads();
-        // ---- stage Q patch (units of (row, 64-column pass); 8 independent loads per batch)
+        // ---- stage Q patch: scalar incremental row bookkeeping, lane-invariant column part, buffer loads (zero fill)
         {
             const int qy0 = gy0 * a.S - a.pad, qx0 = gx0 * a.S - a.pad;
-            const float *src = a.Q + ((int64_t)n * a.QCtot + a.q_base + c0) * a.QH * a.QW;
-            const int lnp = (a.PWq > 64) ? 1 : 0, units = (a.CK * a.PHq) << lnp;
-            for (int ub = wave; ub < units; ub += 32) {
-                float v[8];
-                int dst[8];
+            const unsigned cb = (unsigned)((n * a.QCtot + a.q_base + c0) * a.QH * a.QW) << 2;
+            unsigned qcol_off[2];
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int cc = lane + 64 * ps, ix = qx0 + cc;
+                qcol_off[ps] = (cc < a.PWq && ix >= 0 && ix < a.QW) ? ((unsigned)ix << 2) : OOB;
+            }
+            int ci = 0, r = wave;
+            while (r >= a.PHq) { r -= a.PHq; ++ci; }
+            while (ci < a.CK) {
+                float v[8][2];
+                int dsts[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int u = ub + 4 * k;
-                    v[k] = 0.f;
-                    dst[k] = -1;
-                    if (u < units) {
-                        const int row = u >> lnp, cc = lane + ((u & lnp) << 6);
-                        const int ci = row / a.PHq, r = row - ci * a.PHq;
-                        if (cc < a.PWq) {
-                            const int iy = qy0 + r, ix = qx0 + cc;
-                            dst[k] = ci * a.PS + r * a.RS + ((a.S == 2) ? ((cc & 1) * a.PWH + (cc >> 1)) : cc);
-                            if (ci < nch && iy >= 0 && iy < a.QH && ix >= 0 && ix < a.QW)
-                                v[k] = src[((int64_t)ci * a.QH + iy) * a.QW + ix];
-                        }
+                    dsts[k] = -1;
+                    if (ci < a.CK) {
+                        const int iy = qy0 + r;
+                        const bool rowok = (ci < nch) & (iy >= 0) & (iy < a.QH);
+                        const unsigned soff = cb + ((unsigned)((ci * a.QH + iy) * a.QW) << 2);
+                        dsts[k] = ci * a.PS + r * a.RS;
+                        v[k][0] = bload(rs_q, rowok ? qcol_off[0] : OOB, rowok ? soff : 0u);
+                        if (qpass2) v[k][1] = bload(rs_q, rowok ? qcol_off[1] : OOB, rowok ? soff : 0u);
+                        r += 4;
+                        while (r >= a.PHq) { r -= a.PHq; ++ci; }
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (dst[k] >= 0) qp[dst[k]] = v[k];
+                for (int k = 0; k < 8; ++k) {
+                    if (dsts[k] >= 0) {
+                        if (qcol_dst[0] >= 0) qp[dsts[k] + qcol_dst[0]] = v[k][0];
+                        if (qpass2 && qcol_dst[1] >= 0) qp[dsts[k] + qcol_dst[1]] = v[k][1];
+                    }
+                }
             }
         }
-        // ---- stage P tile transposed: pl[pixel][m]; half-wave = one row of 32 pixels; 8 loads per batch
+        // ---- stage P tile transposed: pl[pixel][m]; half-wave = one row of 32 pixels; 8 buffer loads per batch
         {
             const int npairs = a.BH >> 1;          // row pairs per channel
             const int px = lane & 31, prow = lane >> 5;
             const int total = 32 * MT * npairs;
+            const bool colok = gx0 + px < a.GW;
+            const unsigned pb = (unsigned)((n * a.PCtot + a.m_base + m0) * a.GH * a.GW) << 2;
             for (int ib = wave; ib < total; ib += 32) {
                 float v[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int idx = ib + 4 * k;
                     const int m = idx >> a.lnp, rp = idx - (m << a.lnp);
-                    const int gy = gy0 + rp * 2 + prow, gx = gx0 + px;
-                    v[k] = 0.f;
-                    if (idx < total && m0 + m < a.M && gy < a.GH && gx < a.GW)
-                        v[k] = a.P[(((int64_t)n * a.PCtot + a.m_base + m0 + m) * a.GH + gy) * a.GW + gx];
+                    const int gy = gy0 + rp * 2 + prow;
+                    const bool mok = (idx < total) & (m0 + m < a.M);
+                    const unsigned voff = (colok && gy < a.GH) ? ((unsigned)(gy * a.GW + gx0 + px) << 2) : OOB;
+                    v[k] = bload(rs_p, mok ? voff : OOB, mok ? pb + ((unsigned)(m * a.GH * a.GW) << 2) : 0u);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -830,6 +849,9 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
         a.PSPLIT = psplit;
         const size_t lds = ((size_t)CK * a.PS + (size_t)a.BH * WG_BW * a.COTP) * 4;
         if (lds > 64 * 1024) return DVF_ERR_UNSUPPORTED;
+        if ((int64_t)a.N * a.PCtot * a.GH * a.GW * 4 >= ((int64_t)1 << 31) - 16 ||
+            (int64_t)a.N * a.QCtot * a.QH * a.QW * 4 >= ((int64_t)1 << 31) - 16)
+            return DVF_ERR_UNSUPPORTED;             // 32-bit byte offsets inside the kernel
         const dim3 grid(mtiles, cchunks, psplit);
         if (MT == 2 && NTW == 2) conv_wgrad_kernel<2, 2><<<grid, 256, lds, st>>>(a);
         else if (MT == 2) conv_wgrad_kernel<2, 1><<<grid, 256, lds, st>>>(a);
