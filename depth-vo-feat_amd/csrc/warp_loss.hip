@@ -588,6 +588,136 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const float *map, const
     g_map[(int64_t)n * H * W + (int64_t)y * W + x] = gl * (g1 * w1 + g2 * w2 + g3 * w3);
 }
 
+// ------------------------------------------------------------------ stand-alone geometry helpers (inverse_warp.py API)
+__global__ void pose_vec2mat_kernel(const float *pose, float *out, int n, uint32_t quat) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float R[9];
+    pose_to_R(pose + (int64_t)i * 6, quat != 0, R);
+    float *o = out + (int64_t)i * 12;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        o[r * 4 + 0] = R[r * 3 + 0]; o[r * 4 + 1] = R[r * 3 + 1]; o[r * 4 + 2] = R[r * 3 + 2];
+        o[r * 4 + 3] = pose[(int64_t)i * 6 + r];
+    }
+}
+
+// g_mat [n,3,4] -> workspace layout of pose_finalize_kernel (g_t[3], g_R[9])
+__global__ void mat_grad_to_ws_kernel(const float *g_mat, float *ws, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *g = g_mat + (int64_t)i * 12;
+    float *w = ws + (int64_t)i * 12;
+    w[0] = g[3]; w[1] = g[7]; w[2] = g[11];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w[3 + r * 3 + c] = g[r * 4 + c];
+}
+
+// cam = (Kinv @ (u, v, 1)) * depth   (inverse_warp.py:26-40); BWD: g_depth = sum_c g_cam_c * (Kinv @ (u,v,1))_c
+template <bool BWD>
+__global__ void pixel2cam_kernel(const float *depth, const float *Kinv, const float *g_cam, float *out, int H, int W,
+                                 int64_t total) {
+    const int64_t HW = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int64_t pix = i - (int64_t)b * HW;
+        const float u = (float)(pix % W), v = (float)(pix / W);
+        const float *k = Kinv + (int64_t)b * 9;
+        const float c0 = k[0] * u + k[1] * v + k[2], c1 = k[3] * u + k[4] * v + k[5], c2 = k[6] * u + k[7] * v + k[8];
+        if (!BWD) {
+            const float d = depth[i];
+            float *o = out + (int64_t)b * 3 * HW + pix;
+            o[0] = c0 * d; o[HW] = c1 * d; o[2 * HW] = c2 * d;
+        } else {
+            const float *g = g_cam + (int64_t)b * 3 * HW + pix;
+            out[i] = g[0] * c0 + g[HW] * c1 + g[2 * HW] * c2;
+        }
+    }
+}
+
+// cam [B,3,H,W] -> normalised grid [B,H,W,2]   (inverse_warp.py:43-74)
+__global__ void cam2pixel_fwd_kernel(const float *cam, const float *rot, const float *tr, float *grid, int H, int W,
+                                     int zeros_pad, int64_t total) {
+    const int64_t HW = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const int64_t pix = i - (int64_t)b * HW;
+        const float *c = cam + (int64_t)b * 3 * HW + pix;
+        float p[3] = {c[0], c[HW], c[2 * HW]};
+        if (rot) {
+            const float *r = rot + (int64_t)b * 9;
+            const float x = p[0], y = p[1], z = p[2];
+            p[0] = r[0] * x + r[1] * y + r[2] * z; p[1] = r[3] * x + r[4] * y + r[5] * z; p[2] = r[6] * x + r[7] * y + r[8] * z;
+        }
+        if (tr) { p[0] += tr[b * 3 + 0]; p[1] += tr[b * 3 + 1]; p[2] += tr[b * 3 + 2]; }
+        const float Z = fmaxf(p[2], 1e-3f);
+        float xn = __fsub_rn(__fdiv_rn(2.f * (p[0] / Z), (float)(W - 1)), 1.f);
+        float yn = __fsub_rn(__fdiv_rn(2.f * (p[1] / Z), (float)(H - 1)), 1.f);
+        if (zeros_pad) {
+            if (xn > 1.f || xn < -1.f) xn = 2.f;
+            if (yn > 1.f || yn < -1.f) yn = 2.f;
+        }
+        grid[2 * i] = xn;
+        grid[2 * i + 1] = yn;
+    }
+}
+
+// backward: g_cam per pixel; g_rot (9) and g_tr (3) per batch element through block partials + atomics (ws [B,12])
+__global__ __launch_bounds__(256) void cam2pixel_bwd_kernel(const float *cam, const float *rot, const float *tr,
+                                                            const float *g_grid, float *g_cam, float *ws, int H, int W,
+                                                            int zeros_pad, int chunks) {
+    __shared__ float red[4][12];
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const int HW = H * W, per = (HW + chunks - 1) / chunks, beg = chunk * per, end = min(HW, beg + per);
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int pix = beg + threadIdx.x; pix < end; pix += 256) {
+        const float *c = cam + (int64_t)b * 3 * HW + pix;
+        const float x = c[0], y = c[HW], z = c[2 * HW];
+        float p[3] = {x, y, z};
+        float r[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (rot) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) r[k] = rot[(int64_t)b * 9 + k];
+            p[0] = r[0] * x + r[1] * y + r[2] * z; p[1] = r[3] * x + r[4] * y + r[5] * z; p[2] = r[6] * x + r[7] * y + r[8] * z;
+        }
+        if (tr) { p[0] += tr[b * 3 + 0]; p[1] += tr[b * 3 + 1]; p[2] += tr[b * 3 + 2]; }
+        const bool zpass = p[2] >= 1e-3f;
+        const float Z = fmaxf(p[2], 1e-3f), xq = p[0] / Z, yq = p[1] / Z;
+        const float xn = __fsub_rn(__fdiv_rn(2.f * xq, (float)(W - 1)), 1.f), yn = __fsub_rn(__fdiv_rn(2.f * yq, (float)(H - 1)), 1.f);
+        float gx = g_grid[2 * ((int64_t)b * HW + pix)], gy = g_grid[2 * ((int64_t)b * HW + pix) + 1];
+        if (zeros_pad) {
+            if (xn > 1.f || xn < -1.f) gx = 0.f;
+            if (yn > 1.f || yn < -1.f) gy = 0.f;
+        }
+        const float gxq = gx * 2.f / (float)(W - 1), gyq = gy * 2.f / (float)(H - 1);
+        const float gp0 = gxq / Z, gp1 = gyq / Z, gp2 = zpass ? -(gxq * xq + gyq * yq) / Z : 0.f;
+        if (g_cam) {
+            float *g = g_cam + (int64_t)b * 3 * HW + pix;
+            g[0] = r[0] * gp0 + r[3] * gp1 + r[6] * gp2;
+            g[HW] = r[1] * gp0 + r[4] * gp1 + r[7] * gp2;
+            g[2 * HW] = r[2] * gp0 + r[5] * gp1 + r[8] * gp2;
+        }
+        acc[0] += gp0; acc[1] += gp1; acc[2] += gp2;
+        acc[3] += gp0 * x; acc[4] += gp0 * y; acc[5] += gp0 * z;
+        acc[6] += gp1 * x; acc[7] += gp1 * y; acc[8] += gp1 * z;
+        acc[9] += gp2 * x; acc[10] += gp2 * y; acc[11] += gp2 * z;
+    }
+    if (!ws) return;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const float s = wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12)
+        atomicAdd(&ws[(int64_t)b * 12 + threadIdx.x],
+                  (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
 template <typename F>
 int dispatch_mode(uint32_t flags, F &&f) {
     const bool border = flags & DVF_PAD_BORDER, align = flags & DVF_ALIGN_CORNERS;
@@ -716,6 +846,65 @@ int dvf_photo_loss_bwd(const float *tgt, const float *const *srcs, int V, const 
         pose_finalize_kernel<<<(V * B + 63) / 64, 64, 0, st>>>(pose, pose_ws, g_pose, V * B, flags & DVF_ROT_QUAT);
         DVF_LAUNCH_CHECK();
     }
+    return DVF_OK;
+}
+
+int dvf_pose_vec2mat_fwd(const float *pose, float *out, int n, uint32_t flags, void *stream) {
+    if (!pose || !out || n <= 0) return DVF_ERR_INVALID_ARG;
+    pose_vec2mat_kernel<<<(n + 63) / 64, 64, 0, dvf_stream(stream)>>>(pose, out, n, flags & DVF_ROT_QUAT);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+int dvf_pose_vec2mat_bwd(const float *pose, const float *g_mat, float *g_pose, float *ws, int n, uint32_t flags,
+                         void *stream) {
+    if (!pose || !g_mat || !g_pose || !ws || n <= 0) return DVF_ERR_INVALID_ARG;
+    hipStream_t st = dvf_stream(stream);
+    mat_grad_to_ws_kernel<<<(n + 63) / 64, 64, 0, st>>>(g_mat, ws, n);
+    DVF_LAUNCH_CHECK();
+    pose_finalize_kernel<<<(n + 63) / 64, 64, 0, st>>>(pose, ws, g_pose, n, flags & DVF_ROT_QUAT);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+int dvf_pixel2cam_fwd(const float *depth, const float *Kinv, float *cam, int B, int H, int W, void *stream) {
+    if (!depth || !Kinv || !cam || B <= 0 || H <= 0 || W <= 0) return DVF_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)B * H * W;
+    const int nb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    pixel2cam_kernel<false><<<nb, 256, 0, dvf_stream(stream)>>>(depth, Kinv, nullptr, cam, H, W, total);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+int dvf_pixel2cam_bwd(const float *Kinv, const float *g_cam, float *g_depth, int B, int H, int W, void *stream) {
+    if (!Kinv || !g_cam || !g_depth || B <= 0 || H <= 0 || W <= 0) return DVF_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)B * H * W;
+    const int nb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    pixel2cam_kernel<true><<<nb, 256, 0, dvf_stream(stream)>>>(nullptr, Kinv, g_cam, g_depth, H, W, total);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+int dvf_cam2pixel_fwd(const float *cam, const float *rot, const float *tr, float *grid, int B, int H, int W,
+                      uint32_t flags, void *stream) {
+    if (!cam || !grid || B <= 0 || H < 2 || W < 2) return DVF_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)B * H * W;
+    const int nb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    cam2pixel_fwd_kernel<<<nb, 256, 0, dvf_stream(stream)>>>(cam, rot, tr, grid, H, W, (flags & DVF_PAD_BORDER) ? 0 : 1, total);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+int dvf_cam2pixel_bwd(const float *cam, const float *rot, const float *tr, const float *g_grid, float *g_cam,
+                      float *g_rot_tr_ws, int B, int H, int W, uint32_t flags, void *stream) {
+    if (!cam || !g_grid || B <= 0 || H < 2 || W < 2 || B > 4096) return DVF_ERR_INVALID_ARG;
+    hipStream_t st = dvf_stream(stream);
+    if (g_rot_tr_ws && hipMemsetAsync(g_rot_tr_ws, 0, sizeof(float) * 12 * B, st) != hipSuccess) return DVF_ERR_LAUNCH;
+    int chunks = (H * W + 8191) / 8192;
+    if (chunks < 1) chunks = 1;
+    cam2pixel_bwd_kernel<<<B * chunks, 256, 0, st>>>(cam, rot, tr, g_grid, g_cam, g_rot_tr_ws, H, W,
+                                                     (flags & DVF_PAD_BORDER) ? 0 : 1, chunks);
+    DVF_LAUNCH_CHECK();
     return DVF_OK;
 }
 

@@ -42,6 +42,12 @@ SIGNATURES = {
     "dvf_inverse_warp_fwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_u32, c_fp]),
     "dvf_inverse_warp_bwd": (c_i, [c_fp] * 10 + [c_i] * 4 + [c_u32, c_fp]),
     "dvf_pose_ws_floats": (c_i64, [c_i, c_i]),
+    "dvf_pose_vec2mat_fwd": (c_i, [c_fp, c_fp, c_i, c_u32, c_fp]),
+    "dvf_pose_vec2mat_bwd": (c_i, [c_fp] * 4 + [c_i, c_u32, c_fp]),
+    "dvf_pixel2cam_fwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_fp]),
+    "dvf_pixel2cam_bwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_fp]),
+    "dvf_cam2pixel_fwd": (c_i, [c_fp] * 4 + [c_i] * 3 + [c_u32, c_fp]),
+    "dvf_cam2pixel_bwd": (c_i, [c_fp] * 6 + [c_i] * 3 + [c_u32, c_fp]),
     "dvf_photo_loss_fwd": (c_i, [c_fp, c_pp, c_i] + [c_fp] * 8 + [c_i] * 4 + [c_u32, c_fp]),
     "dvf_photo_partials_floats": (c_i64, [c_i] * 4),
     "dvf_photo_loss_bwd": (c_i, [c_fp, c_pp, c_i] + [c_fp] * 9 + [c_pp, c_fp, c_fp] + [c_i] * 4 + [c_u32, c_fp]),

@@ -163,3 +163,81 @@ class ExplainabilityLossFn(torch.autograd.Function):
                     "dvf_bce_ones_bwd")
             grads.append(g)
         return tuple(grads)
+
+
+class PoseVec2MatFn(torch.autograd.Function):
+    """pose_vec2mat (reference inverse_warp.py:141-157): [n,6] -> [n,3,4]."""
+
+    @staticmethod
+    def forward(ctx, vec, flags):
+        vec = _f32c(vec)
+        n = vec.shape[0]
+        out = torch.empty((n, 3, 4), device=vec.device, dtype=torch.float32)
+        L.check(L.lib().dvf_pose_vec2mat_fwd(L.dev(vec, "vec"), L.dev(out), n, flags, L.stream()), "dvf_pose_vec2mat_fwd")
+        ctx.save_for_backward(vec)
+        ctx.flags = flags
+        return out
+
+    @staticmethod
+    def backward(ctx, gmat):
+        (vec,) = ctx.saved_tensors
+        n = vec.shape[0]
+        g = torch.empty_like(vec)
+        ws = torch.empty(n * 12, device=vec.device)
+        L.check(L.lib().dvf_pose_vec2mat_bwd(L.dev(vec), L.dev(_f32c(gmat), "grad_out"), L.dev(g), L.dev(ws), n, ctx.flags,
+                                             L.stream()), "dvf_pose_vec2mat_bwd")
+        return g, None
+
+
+class Pixel2CamFn(torch.autograd.Function):
+    """pixel2cam (reference inverse_warp.py:26-40)."""
+
+    @staticmethod
+    def forward(ctx, depth, Kinv):
+        depth, Kinv = _f32c(depth), _f32c(Kinv)
+        B, H, W = depth.shape
+        cam = torch.empty((B, 3, H, W), device=depth.device, dtype=torch.float32)
+        L.check(L.lib().dvf_pixel2cam_fwd(L.dev(depth, "depth"), L.dev(Kinv, "intrinsics_inv"), L.dev(cam), B, H, W,
+                                          L.stream()), "dvf_pixel2cam_fwd")
+        ctx.save_for_backward(Kinv)
+        ctx.shape = (B, H, W)
+        return cam
+
+    @staticmethod
+    def backward(ctx, gcam):
+        (Kinv,) = ctx.saved_tensors
+        B, H, W = ctx.shape
+        g = torch.empty((B, H, W), device=gcam.device, dtype=torch.float32)
+        L.check(L.lib().dvf_pixel2cam_bwd(L.dev(Kinv), L.dev(_f32c(gcam), "grad_out"), L.dev(g), B, H, W, L.stream()),
+                "dvf_pixel2cam_bwd")
+        return g, None
+
+
+class Cam2PixelFn(torch.autograd.Function):
+    """cam2pixel (reference inverse_warp.py:43-74): cam [B,3,H,W] -> normalised grid [B,H,W,2]."""
+
+    @staticmethod
+    def forward(ctx, cam, rot, tr, flags):
+        cam = _f32c(cam)
+        rot = _f32c(rot) if rot is not None else None
+        tr = _f32c(tr).reshape(-1, 3) if tr is not None else None
+        B, _, H, W = cam.shape
+        grid = torch.empty((B, H, W, 2), device=cam.device, dtype=torch.float32)
+        L.check(L.lib().dvf_cam2pixel_fwd(L.dev(cam, "cam_coords"), L.dev(rot, "proj_c2p_rot"), L.dev(tr, "proj_c2p_tr"),
+                                          L.dev(grid), B, H, W, flags, L.stream()), "dvf_cam2pixel_fwd")
+        ctx.save_for_backward(cam, rot, tr)
+        ctx.flags = flags
+        return grid
+
+    @staticmethod
+    def backward(ctx, ggrid):
+        cam, rot, tr = ctx.saved_tensors
+        B, _, H, W = cam.shape
+        gcam = torch.empty_like(cam) if ctx.needs_input_grad[0] else None
+        need_rt = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        ws = torch.empty((B, 12), device=cam.device) if need_rt else None
+        L.check(L.lib().dvf_cam2pixel_bwd(L.dev(cam), L.dev(rot), L.dev(tr), L.dev(_f32c(ggrid), "grad_out"), L.dev(gcam),
+                                          L.dev(ws), B, H, W, ctx.flags, L.stream()), "dvf_cam2pixel_bwd")
+        g_rot = ws[:, 3:].reshape(B, 3, 3) if (rot is not None and ctx.needs_input_grad[1]) else None
+        g_tr = ws[:, :3].reshape(B, 3, 1) if (tr is not None and ctx.needs_input_grad[2]) else None
+        return gcam, g_rot, g_tr, None

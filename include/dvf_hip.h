@@ -62,6 +62,24 @@ int dvf_inverse_warp_bwd(const float *img, const float *depth, const float *pose
                          void *stream);
 int64_t dvf_pose_ws_floats(int V, int B);
 
+/* ---------------------------------------------------------------- stand-alone geometry helpers
+ * The public building blocks of inverse_warp.py, for callers that use them directly (the fused kernels above do
+ * not go through these).
+ *   pose_vec2mat (inverse_warp.py:141-157; euler2mat :77-114, quat2mat :117-138): pose [n,6] -> [n,3,4];
+ *     backward: g_mat [n,3,4] -> g_pose [n,6], ws = n*12 floats.
+ *   pixel2cam (:26-40): depth [B,H,W], Kinv [B,3,3] -> cam [B,3,H,W]; backward -> g_depth.
+ *   cam2pixel (:43-74): cam [B,3,H,W], rot [B,3,3] or NULL, tr [B,3] or NULL -> grid [B,H,W,2] (x_n, y_n);
+ *     backward: g_cam [B,3,H,W] (may be NULL) and g_rot_tr_ws [B,12] = (g_tr[3], g_rot[9]) (may be NULL). */
+int dvf_pose_vec2mat_fwd(const float *pose, float *out, int n, uint32_t flags, void *stream);
+int dvf_pose_vec2mat_bwd(const float *pose, const float *g_mat, float *g_pose, float *ws, int n, uint32_t flags,
+                         void *stream);
+int dvf_pixel2cam_fwd(const float *depth, const float *Kinv, float *cam, int B, int H, int W, void *stream);
+int dvf_pixel2cam_bwd(const float *Kinv, const float *g_cam, float *g_depth, int B, int H, int W, void *stream);
+int dvf_cam2pixel_fwd(const float *cam, const float *rot, const float *tr, float *grid, int B, int H, int W,
+                      uint32_t flags, void *stream);
+int dvf_cam2pixel_bwd(const float *cam, const float *rot, const float *tr, const float *g_grid, float *g_cam,
+                      float *g_rot_tr_ws, int B, int H, int W, uint32_t flags, void *stream);
+
 /* ---------------------------------------------------------------- fused warp + photometric L1
  * Replaces the body of loss_functions.photometric_reconstruction_loss (loss_functions.py:7-20) and of
  * one_scale() in loss_functions_sfm.photometric_reconstruction_loss (loss_functions_sfm.py:10-36):

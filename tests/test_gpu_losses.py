@@ -190,3 +190,50 @@ def test_photometric_view_linearity_full_size():
     ref = ol.photometric_reconstruction_loss(tgt.cpu(), s0.cpu(), s1.cpu(), depth.cpu(), pose[0].cpu(), pose[1].cpu(),
                                              K.cpu(), Kinv.cpu())
     assert rel_err(both, ref) < TOL
+
+
+@pytest.mark.parametrize("rot", ["euler", "quat"])
+def test_geometry_helpers_vs_oracle(rot):
+    """The stand-alone building blocks of inverse_warp.py (pose_vec2mat / euler2mat / quat2mat / pixel2cam /
+    cam2pixel / set_id_grid) against the oracle, values and gradients."""
+    import inverse_warp as iw
+    gen = torch.Generator().manual_seed(17)
+    b, h, w = 2, 24, 40
+    vec = torch.randn(b, 6, generator=gen) * 0.2
+    depth = torch.rand(b, h, w, generator=gen) * 20 + 2
+    K, Kinv = _kitti_K(b, h, w)
+    gm = torch.randn(b, 3, 4, generator=gen)
+    rv = vec.clone().requires_grad_(True)
+    ref = og.pose_vec2mat(rv, rot)
+    (ref * gm).sum().backward()
+    gv = vec.clone().to(DEV).requires_grad_(True)
+    out = iw.pose_vec2mat(gv, rot)
+    (out * gm.to(DEV)).sum().backward()
+    assert rel_err(out, ref) < 1e-6 and rel_err(gv.grad, rv.grad) < 1e-5
+    fn_o, fn_g = (og.euler2mat, iw.euler2mat) if rot == "euler" else (og.quat2mat, iw.quat2mat)
+    assert rel_err(fn_g(vec[:, 3:].to(DEV)), fn_o(vec[:, 3:])) < 1e-6
+    # pixel2cam
+    rd = depth.clone().requires_grad_(True)
+    cam_ref = og.pixel2cam(rd, Kinv)
+    gc = torch.randn(cam_ref.shape, generator=gen)
+    (cam_ref * gc).sum().backward()
+    gd = depth.clone().to(DEV).requires_grad_(True)
+    cam = iw.pixel2cam(gd, Kinv.to(DEV))
+    (cam * gc.to(DEV)).sum().backward()
+    assert rel_err(cam, cam_ref) < 1e-6 and rel_err(gd.grad, rd.grad) < 1e-5
+    # cam2pixel (zeros and border), gradients to cam / rot / tr
+    for pad in ("zeros", "border"):
+        proj = (K @ og.pose_vec2mat(vec * 0.2, rot))
+        leaves = [cam_ref.detach().clone().requires_grad_(True), proj[:, :, :3].clone().requires_grad_(True),
+                  proj[:, :, -1:].clone().requires_grad_(True)]
+        gref = og.cam2pixel(leaves[0], leaves[1], leaves[2], pad)
+        gg = torch.randn(gref.shape, generator=gen)
+        (gref * gg).sum().backward()
+        dl = [x.detach().clone().to(DEV).requires_grad_(True) for x in leaves]
+        gout = iw.cam2pixel(dl[0], dl[1], dl[2], pad)
+        (gout * gg.to(DEV)).sum().backward()
+        assert rel_err(gout, gref) < 1e-5
+        for a, r, nm in zip(dl, leaves, ("cam", "rot", "tr")):
+            assert rel_err(a.grad, r.grad) < TOL, (pad, nm)
+    iw.set_id_grid(depth.to(DEV))
+    assert rel_err(iw.pixel_coords, og.pixel_grid(h, w, torch.float32)) == 0.0
