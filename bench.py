@@ -45,17 +45,22 @@ def build(args, device, world):
     rank = dist.get_rank() if world > 1 else 0
     batch = synthetic_batch(args.batch, args.height, args.width, seed=1234, rank=rank, device=device)
     # unsupervise.py:241  Adam(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)
+    ddp = world > 1 or args.force_ddp
     opt = FlatAdam(list(pose_net.parameters()) + list(disp_net.parameters()), lr=1e-3, weight_decay=1e-8,
-                   world_size=world)
+                   world_size=world, overlap=args.no_graph, always_reduce=ddp)
 
-    def step():
+    def fwd_bwd():
         loss, terms = unsupervise_losses(disp_net, pose_net, batch)
         opt.zero_grad()
         loss.backward()
-        opt.step()
         return (terms["total"], terms["img"], terms["smooth"])
 
-    return step, opt
+    def step():
+        out = fwd_bwd()
+        opt.step()                      # (gradient all-reduce +) fused Adam
+        return out
+
+    return step, fwd_bwd, opt, ddp
 
 
 def measure_kernels(step):
@@ -116,6 +121,10 @@ def main():
     ap.add_argument("--width", type=int, default=832)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--force-ddp", action="store_true", help="run the multi-GPU exchange path even with one rank")
+    ap.add_argument("--graph-ddp", action="store_true",
+                    help="multi-GPU: replay forward+backward from a HIP graph and all-reduce afterwards (no overlap); "
+                         "default for N>1 is eager launches with the all-reduce overlapped with backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -127,8 +136,9 @@ def main():
         sys.exit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -138,16 +148,27 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     log("building models")
-    step, opt = build(args, device, world)
-    use_graph = (world == 1) and not args.no_graph
+    if (world > 1 or args.force_ddp) and not args.graph_ddp:
+        args.no_graph = True
+    step, fwd_bwd, opt, ddp = build(args, device, world)
+    use_graph = not args.no_graph
     from dvf.engine import GraphedStep
     if use_graph:
         log("eager step 1")
         step()
         torch.cuda.synchronize()
         log("capturing HIP graph")
-        runner = GraphedStep(step, [], warmup=1)
-        run = runner
+        if not ddp:
+            run = GraphedStep(step, [], warmup=1)              # whole step: forward + backward + Adam
+        else:
+            # forward + backward replay from the graph; the RCCL all-reduce of the gradient arena and the fused
+            # Adam are enqueued behind it on the same stream (collectives are not captured)
+            graph = GraphedStep(fwd_bwd, [], warmup=0)
+
+            def run():
+                out = graph()
+                opt.step()
+                return out
     else:
         run = step
     log("warm-up")
@@ -183,7 +204,7 @@ def main():
             "config": {"workload": "cfg2: DispNetS+PoseExpNet joint step, spatial+temporal photometric (V=2) + "
                                    "10*smooth, Adam; %dx%d, batch %d per GPU" % (args.height, args.width, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "launch": "hipgraph" if use_graph else "eager"},
+                       "launch": ("hipgraph" if use_graph else "eager") + ("+rccl-allreduce" if ddp else "")},
             "final_loss": loss,
         }
     log("timed region done: %.2f ms/step" % (1e3 * dt / args.steps))
@@ -219,12 +240,12 @@ def main():
         result["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(ks.items())}
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.force_ddp and not args.no_cpu_baseline:
         log("cpu baseline")
         result["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if world > 1 or args.force_ddp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -57,7 +57,7 @@ def run_training(args, nets, loss_fn, lr, betas, weight_decay, term_names, ckpt_
     """Epoch loop.  ``loss_fn(batch) -> (loss, terms)``; ``nets``: list of modules in optimizer-group order."""
     rank, world, device = args._rank, args._world, args._device
     params = [p for net in nets for p in net.parameters()]
-    opt = FlatAdam(params, lr=lr, betas=betas, weight_decay=weight_decay, world_size=world)
+    opt = FlatAdam(params, lr=lr, betas=betas, weight_decay=weight_decay, world_size=world, overlap=True)
     batch = synthetic_batch(args.batch_size, args.height, args.width, seed=1234 + args.seed, rank=rank, n_views=n_views,
                             device=device)
     acc = torch.zeros(len(term_names), device=device)            # device-side running sums: no per-step .item()

@@ -22,13 +22,18 @@ class FlatAdam:
     """torch.optim.Adam over flat arenas.  ``params``: iterable of nn.Parameter (all nets together)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world_size=1,
-                 bucket_mb=25.0, process_group=None):
+                 bucket_mb=25.0, process_group=None, overlap=True, always_reduce=False):
+        """overlap=True: buckets are all-reduced on a side stream from inside backward (eager execution).
+        overlap=False: backward only marks gradients; ``step()`` all-reduces the buckets on the current stream --
+        the mode used when forward+backward are replayed from a HIP graph.  always_reduce: run the exchange even
+        with world_size 1 (single-GPU rehearsal of the multi-GPU code path)."""
         self.params = [p for p in params if p.requires_grad][::-1]       # backward-ready order
         if not self.params:
             raise ValueError("no parameters")
         dev = self.params[0].device
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
         self.world_size, self.group = int(world_size), process_group
+        self.overlap, self.exchange = bool(overlap), (int(world_size) > 1 or always_reduce)
         sizes = [p.numel() for p in self.params]
         # 64-float (256 B) aligned offsets: every view starts on its own cache lines
         self.offsets, off = [], 0
@@ -61,7 +66,7 @@ class FlatAdam:
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
                 p._dvf_bucket = bi
-        self._comm_stream = torch.cuda.Stream(device=dev) if (self.world_size > 1 and dev.type == "cuda") else None
+        self._comm_stream = torch.cuda.Stream(device=dev) if (self.exchange and self.overlap and dev.type == "cuda") else None
         self._ranges = None
         self._reset_pending()
 
@@ -77,7 +82,7 @@ class FlatAdam:
             p._dvf_touched = True
             p.grad = p._dvf_grad            # expose it the torch way
             self._ranges = None
-        if self.world_size <= 1:
+        if not (self.exchange and self.overlap):
             return
         b = self.buckets[p._dvf_bucket]
         b["pending"] -= 1
@@ -87,7 +92,7 @@ class FlatAdam:
     def _launch_bucket(self, b):
         b["launched"] = True
         grads = self.flat_g[b["start"]:b["end"]]
-        if self._comm_stream is None:                       # CPU tensors (gloo): synchronous
+        if self._comm_stream is None:                       # CPU tensors (gloo) or overlap=False: current stream
             dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
             return
         ev = torch.cuda.Event()
@@ -118,7 +123,7 @@ class FlatAdam:
     def synchronize_grads(self):
         """Finish the data-parallel exchange: launch what backward could not (first step, stragglers) and make the
         compute stream wait for the side stream."""
-        if self.world_size <= 1:
+        if not self.exchange:
             return
         self._touched_ranges()
         for b in self.buckets:
