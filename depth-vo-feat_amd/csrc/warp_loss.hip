@@ -16,7 +16,8 @@
 namespace {
 
 constexpr int TX = 64;   // pixels along a row per wave
-constexpr int TY = 4;    // rows per block (one wave each)
+constexpr int TY = 4;    // rows per block pass (one wave each)
+constexpr int RPT = 1;   // row passes per block (measured: 4 is slower -- fewer, longer blocks -- despite 4x fewer reductions)
 
 struct ViewGeo {         // per (view, batch element); built once per block in LDS
     float A[9];          // K @ R           inverse_warp.py:188 (rotation part)
@@ -123,15 +124,33 @@ __device__ __forceinline__ Samp project(const ViewGeo &g, float cx, float cy, fl
 
 struct Taps { float nw, ne, sw, se; };
 
-__device__ __forceinline__ Taps gather(const float *__restrict__ plane, const Samp &s, int W, int H) {
-    Taps t;
+// Tap addressing of one (pixel, view), shared by all channels.  The two taps of a row are adjacent, so each row is ONE
+// unconditional 8-byte load (4-byte aligned global_load_dwordx2) from a clamped, always valid pair position; the
+// warp kernels are bound by the number of vector-memory instructions, not by bytes.
+struct __attribute__((packed, aligned(4))) Pair { float x, y; };
+struct TapAddr { int o_top, o_bot; bool straight; bool v_nw, v_ne, v_sw, v_se; };
+
+__device__ __forceinline__ TapAddr tap_addr(const Samp &s, int W, int H) {
+    TapAddr a;
     const bool xin0 = (unsigned)s.x0 < (unsigned)W, xin1 = (unsigned)(s.x0 + 1) < (unsigned)W;
     const bool yin0 = (unsigned)s.y0 < (unsigned)H, yin1 = (unsigned)(s.y0 + 1) < (unsigned)H;
-    const float *r0 = plane + (int64_t)s.y0 * W + s.x0;
-    t.nw = (xin0 && yin0) ? r0[0] : 0.f;
-    t.ne = (xin1 && yin0) ? r0[1] : 0.f;
-    t.sw = (xin0 && yin1) ? r0[W] : 0.f;
-    t.se = (xin1 && yin1) ? r0[W + 1] : 0.f;
+    const int xb = min(max(s.x0, 0), W - 2);               // pair (xb, xb+1) is always inside the row
+    const int y0 = min(max(s.y0, 0), H - 1), y1 = min(max(s.y0 + 1, 0), H - 1);
+    a.o_top = y0 * W + xb;
+    a.o_bot = y1 * W + xb;
+    a.straight = (s.x0 == xb);                             // else the pair is shifted by one (x0 = -1 or W-1)
+    a.v_nw = xin0 && yin0; a.v_ne = xin1 && yin0; a.v_sw = xin0 && yin1; a.v_se = xin1 && yin1;
+    return a;
+}
+
+__device__ __forceinline__ Taps gather(const float *__restrict__ plane, const TapAddr &a) {
+    Taps t;
+    const Pair top = *reinterpret_cast<const Pair *>(plane + a.o_top);
+    const Pair bot = *reinterpret_cast<const Pair *>(plane + a.o_bot);
+    t.nw = a.v_nw ? (a.straight ? top.x : top.y) : 0.f;
+    t.ne = a.v_ne ? (a.straight ? top.y : top.x) : 0.f;
+    t.sw = a.v_sw ? (a.straight ? bot.x : bot.y) : 0.f;
+    t.se = a.v_se ? (a.straight ? bot.y : bot.x) : 0.f;
     return t;
 }
 
@@ -171,17 +190,21 @@ __device__ __forceinline__ void block_setup(const PhotoArgs &a, int b, int tid, 
     __syncthreads();
 }
 
-template <bool BORDER, bool ALIGN>
+template <bool BORDER, bool ALIGN, int NV>
 __global__ __launch_bounds__(256) void photo_fwd_kernel(PhotoArgs a) {
     __shared__ ViewGeo geo[DVF_MAX_VIEWS];
     __shared__ float kinv[9];
     __shared__ float red[TY][DVF_MAX_VIEWS];
     const int b = blockIdx.z, tid = threadIdx.y * TX + threadIdx.x;
     block_setup(a, b, tid, geo, kinv, nullptr);
-    const int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
+    const int x = blockIdx.x * TX + threadIdx.x;
     const int W = a.W, H = a.H, C = a.C;
     const int64_t HW = (int64_t)H * W;
-    float lsum[DVF_MAX_VIEWS] = {0.f, 0.f, 0.f, 0.f};
+    float lsum[NV];
+#pragma unroll
+    for (int vi = 0; vi < NV; ++vi) lsum[vi] = 0.f;
+    for (int rp = 0; rp < RPT; ++rp) {
+    const int y = (blockIdx.y * RPT + rp) * TY + threadIdx.y;
     if (x < W && y < H) {
         const int64_t pix = (int64_t)y * W + x;
         const float d = a.depth[(int64_t)b * HW + pix];
@@ -191,26 +214,51 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(PhotoArgs a) {
         const float cy = (kinv[3] * u + kinv[4] * v + kinv[5]) * d;
         const float cz = (kinv[6] * u + kinv[7] * v + kinv[8]) * d;
         const float *tg = a.tgt + (int64_t)b * C * HW + pix;
+        // all views are projected first, then every channel group gathers for ALL views at once: with V = 2 and
+        // 4 channels that is 32 source loads + 4 target loads in flight per lane instead of 4
+        Samp s[NV];
+        TapAddr ta[NV];
+        float acc[NV];
+        bool nz[NV];
 #pragma unroll
-        for (int vi = 0; vi < DVF_MAX_VIEWS; ++vi) {
-            if (vi >= a.V) break;
-            const Samp s = project<BORDER, ALIGN>(geo[vi], cx, cy, cz, W, H);
-            const float *sp = a.src[vi] + (int64_t)b * C * HW;
-            float acc = 0.f;
-            bool nz = false;
-            for (int c = 0; c < C; ++c) {
-                const Taps t = gather(sp + c * HW, s, W, H);
-                const float wv = blend(t, s);
-                nz |= (wv != 0.f);                           // loss_functions.py:11  (warped == 0).prod(1)
-                acc += fabsf(tg[c * HW] - wv);               // :12-13
+        for (int vi = 0; vi < NV; ++vi) {
+            s[vi] = project<BORDER, ALIGN>(geo[vi], cx, cy, cz, W, H);
+            ta[vi] = tap_addr(s[vi], W, H);
+            acc[vi] = 0.f;
+            nz[vi] = false;
+        }
+        for (int c = 0; c < C; c += 4) {
+            Taps t[NV][4];
+            float tv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cc = min(c + u, C - 1);
+                tv[u] = tg[cc * HW];
+#pragma unroll
+                for (int vi = 0; vi < NV; ++vi) t[vi][u] = gather(a.src[vi] + ((int64_t)b * C + cc) * HW, ta[vi]);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c + u < C) {
+#pragma unroll
+                    for (int vi = 0; vi < NV; ++vi) {
+                        const float wv = blend(t[vi][u], s[vi]);
+                        nz[vi] |= (wv != 0.f);               // loss_functions.py:11  (warped == 0).prod(1)
+                        acc[vi] += fabsf(tv[u] - wv);        // :12-13
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int vi = 0; vi < NV; ++vi) {
             float m = 1.f;
-            if (a.mask) m = fabsf(a.mask[((int64_t)b * a.V + vi) * HW + pix]);   // loss_functions_sfm.py:30-31
-            lsum[vi] = nz ? acc * m : 0.f;
+            if (a.mask) m = fabsf(a.mask[((int64_t)b * NV + vi) * HW + pix]);   // loss_functions_sfm.py:30-31
+            lsum[vi] += nz[vi] ? acc[vi] * m : 0.f;
         }
     }
+    }
 #pragma unroll
-    for (int vi = 0; vi < DVF_MAX_VIEWS; ++vi) {
+    for (int vi = 0; vi < NV; ++vi) {
         const float r = wave_sum(lsum[vi]);
         if (threadIdx.x == 0) red[threadIdx.y][vi] = r;
     }
@@ -241,17 +289,65 @@ __global__ __launch_bounds__(256) void photo_reduce_kernel(const float *partials
 }
 
 // Reduce 12 values per view over the block and add them to pose_ws[(v*B+b)*12 + k].
+// Wave stage = packed butterfly: at every step a lane hands HALF of its values to its partner and keeps the sum of
+// the other half, so 24 values cost 12+6+3 exchanges plus 3x3 plain steps (30 cross-lane ops instead of 24 x 6).
 template <int NV>
 __device__ __forceinline__ void reduce_pose_partials(float (&acc)[NV][12], int V, int B, int b, float *pose_ws,
                                                      float (*red)[DVF_MAX_VIEWS * 12]) {
+    constexpr int N = NV * 12;
+    float v[N];
 #pragma unroll
-    for (int vi = 0; vi < NV; ++vi) {
-        if (vi >= V) break;
+    for (int vi = 0; vi < NV; ++vi)
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const float r = wave_sum(acc[vi][k]);
-            if (threadIdx.x == 0) red[threadIdx.y][vi * 12 + k] = r;
+        for (int k = 0; k < 12; ++k) v[vi * 12 + k] = acc[vi][k];
+    const int lane = threadIdx.x;                          // blockDim.x == 64: one wave per threadIdx.y
+    // halving steps on lane bits 5, 4, 3 (as long as the count stays even)
+    int base = 0;                                          // original index of v[0] in this lane
+    constexpr int N1 = N / 2, N2 = (N % 4 == 0) ? N / 4 : N1, N3 = (N % 8 == 0) ? N / 8 : N2;
+    {
+        const bool up = lane & 32;
+#pragma unroll
+        for (int i = 0; i < N1; ++i) {
+            const float send = up ? v[i] : v[i + N1], keep = up ? v[i + N1] : v[i];
+            v[i] = keep + __shfl_xor(send, 32, 64);
         }
+        base += up ? N1 : 0;
+    }
+    if (N2 != N1) {
+        const bool up = lane & 16;
+#pragma unroll
+        for (int i = 0; i < N2; ++i) {
+            const float send = up ? v[i] : v[i + N2], keep = up ? v[i + N2] : v[i];
+            v[i] = keep + __shfl_xor(send, 16, 64);
+        }
+        base += up ? N2 : 0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < N1; ++i) v[i] += __shfl_xor(v[i], 16, 64);
+    }
+    if (N3 != N2) {
+        const bool up = lane & 8;
+#pragma unroll
+        for (int i = 0; i < N3; ++i) {
+            const float send = up ? v[i] : v[i + N3], keep = up ? v[i + N3] : v[i];
+            v[i] = keep + __shfl_xor(send, 8, 64);
+        }
+        base += up ? N3 : 0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < N2; ++i) v[i] += __shfl_xor(v[i], 8, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < N3; ++i) {
+        float t = v[i];
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 1, 64);
+        v[i] = t;
+    }
+    if ((lane & 7) == 0) {
+#pragma unroll
+        for (int i = 0; i < N3; ++i) red[threadIdx.y][base + i] = v[i];
     }
     __syncthreads();
     const int tid = threadIdx.y * TX + threadIdx.x;
@@ -261,22 +357,24 @@ __device__ __forceinline__ void reduce_pose_partials(float (&acc)[NV][12], int V
     }
 }
 
-template <bool BORDER, bool ALIGN>
+template <bool BORDER, bool ALIGN, int NV>
 __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
     __shared__ ViewGeo geo[DVF_MAX_VIEWS];
     __shared__ float kinv[9], kmat[9];
     __shared__ float red[TY][DVF_MAX_VIEWS * 12];
     const int b = blockIdx.z, tid = threadIdx.y * TX + threadIdx.x;
     block_setup(a, b, tid, geo, kinv, kmat);
-    const int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
+    const int x = blockIdx.x * TX + threadIdx.x;
     const int W = a.W, H = a.H, C = a.C;
     const int64_t HW = (int64_t)H * W;
     const float scale = a.grad_loss[0] / ((float)a.B * (float)C * (float)H * (float)W);
-    float pacc[DVF_MAX_VIEWS][12];
+    float pacc[NV][12];
 #pragma unroll
-    for (int vi = 0; vi < DVF_MAX_VIEWS; ++vi)
+    for (int vi = 0; vi < NV; ++vi)
 #pragma unroll
         for (int k = 0; k < 12; ++k) pacc[vi][k] = 0.f;
+    for (int rp = 0; rp < RPT; ++rp) {
+    const int y = (blockIdx.y * RPT + rp) * TY + threadIdx.y;
     if (x < W && y < H) {
         const int64_t pix = (int64_t)y * W + x;
         const float d = a.depth[(int64_t)b * HW + pix];
@@ -288,35 +386,61 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
         const float *tg = a.tgt + (int64_t)b * C * HW + pix;
         float gd = 0.f;
         const bool need_tgt = a.g_tgt != nullptr;
+        // pass 1 for ALL views together (see photo_fwd_kernel): d loss / d ix, iy without the validity factor
+        Samp sv[NV];
+        TapAddr tav[NV];
+        float gixv[NV], giyv[NV], absumv[NV], mv[NV];
+        bool nzv[NV];
 #pragma unroll
-        for (int vi = 0; vi < DVF_MAX_VIEWS; ++vi) {
-            if (vi >= a.V) break;
-            const Samp s = project<BORDER, ALIGN>(geo[vi], cx, cy, cz, W, H);
-            const float *sp = a.src[vi] + (int64_t)b * C * HW;
-            float m = 1.f;
-            if (a.mask) m = a.mask[((int64_t)b * a.V + vi) * HW + pix];
-            // pass 1: d loss / d ix, iy (without the validity factor) and the validity itself
-            float gix = 0.f, giy = 0.f, absum = 0.f;
-            bool nz = false;
-            for (int c = 0; c < C; ++c) {
-                const Taps t = gather(sp + c * HW, s, W, H);
-                const float wv = blend(t, s);
-                nz |= (wv != 0.f);
-                const float df = tg[c * HW] - wv;
-                const float sg = sgn(df * m);                // sign of the masked difference
-                absum += fabsf(df);
-                float dox, doy;
-                blend_grad(t, s, dox, doy);
-                gix -= sg * dox;                             // d|.|/d warped = -sign
-                giy -= sg * doy;
+        for (int vi = 0; vi < NV; ++vi) {
+            sv[vi] = project<BORDER, ALIGN>(geo[vi], cx, cy, cz, W, H);
+            tav[vi] = tap_addr(sv[vi], W, H);
+            gixv[vi] = giyv[vi] = absumv[vi] = 0.f;
+            nzv[vi] = false;
+            mv[vi] = a.mask ? a.mask[((int64_t)b * NV + vi) * HW + pix] : 1.f;
+        }
+        for (int c = 0; c < C; c += 4) {
+            Taps t[NV][4];
+            float tv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cc = min(c + u, C - 1);
+                tv[u] = tg[cc * HW];
+#pragma unroll
+                for (int vi = 0; vi < NV; ++vi) t[vi][u] = gather(a.src[vi] + ((int64_t)b * C + cc) * HW, tav[vi]);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c + u < C) {
+#pragma unroll
+                    for (int vi = 0; vi < NV; ++vi) {
+                        const float wv = blend(t[vi][u], sv[vi]);
+                        nzv[vi] |= (wv != 0.f);
+                        const float df = tv[u] - wv;
+                        const float sg = sgn(df * mv[vi]);   // sign of the masked difference
+                        absumv[vi] += fabsf(df);
+                        float dox, doy;
+                        blend_grad(t[vi][u], sv[vi], dox, doy);
+                        gixv[vi] -= sg * dox;                // d|.|/d warped = -sign
+                        giyv[vi] -= sg * doy;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int vi = 0; vi < NV; ++vi) {
+            const Samp &s = sv[vi];
+            const TapAddr &ta = tav[vi];
+            const float *sp = a.src[vi] + (int64_t)b * C * HW;
+            const float m = mv[vi], gix = gixv[vi], giy = giyv[vi], absum = absumv[vi];
+            const bool nz = nzv[vi];
             const float vm = nz ? m * scale : 0.f;           // validity * explainability * upstream / N
-            if (a.g_mask) a.g_mask[((int64_t)b * a.V + vi) * HW + pix] = nz ? absum * sgn(m) * scale : 0.f;
+            if (a.g_mask) a.g_mask[((int64_t)b * NV + vi) * HW + pix] = nz ? absum * sgn(m) * scale : 0.f;
             // pass 2 (features only): grad target and scatter-add grad source
             float *gs = a.g_src[vi];
             if (nz && (need_tgt || gs)) {
                 for (int c = 0; c < C; ++c) {
-                    const Taps t = gather(sp + c * HW, s, W, H);
+                    const Taps t = gather(sp + c * HW, ta);
                     const float df = tg[c * HW] - blend(t, s);
                     const float g = sgn(df * m) * vm;        // d loss / d tgt_c ; d loss / d warped_c = -g
                     if (need_tgt) {
@@ -350,14 +474,15 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
             const float gyx = kmat[0] * gpx + kmat[3] * gpy + kmat[6] * gpz;
             const float gyy = kmat[1] * gpx + kmat[4] * gpy + kmat[7] * gpz;
             const float gyz = kmat[2] * gpx + kmat[5] * gpy + kmat[8] * gpz;
-            pacc[vi][0] = gyx; pacc[vi][1] = gyy; pacc[vi][2] = gyz;
-            pacc[vi][3] = gyx * cx; pacc[vi][4] = gyx * cy; pacc[vi][5] = gyx * cz;
-            pacc[vi][6] = gyy * cx; pacc[vi][7] = gyy * cy; pacc[vi][8] = gyy * cz;
-            pacc[vi][9] = gyz * cx; pacc[vi][10] = gyz * cy; pacc[vi][11] = gyz * cz;
+            pacc[vi][0] += gyx; pacc[vi][1] += gyy; pacc[vi][2] += gyz;
+            pacc[vi][3] += gyx * cx; pacc[vi][4] += gyx * cy; pacc[vi][5] += gyx * cz;
+            pacc[vi][6] += gyy * cx; pacc[vi][7] += gyy * cy; pacc[vi][8] += gyy * cz;
+            pacc[vi][9] += gyz * cx; pacc[vi][10] += gyz * cy; pacc[vi][11] += gyz * cz;
         }
         if (a.g_depth) a.g_depth[(int64_t)b * HW + pix] = gd;
     }
-    if (a.pose_ws) reduce_pose_partials<DVF_MAX_VIEWS>(pacc, a.V, a.B, b, a.pose_ws, red);
+    }
+    if (a.pose_ws) reduce_pose_partials<NV>(pacc, NV, a.B, b, a.pose_ws, red);
 }
 
 // pose_ws[(v*B+b)*12] = (g_t[3], g_R[9]) -> g_pose[(v*B+b)*6] through d R / d (rx,ry,rz).
@@ -445,14 +570,16 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
         const float *sp = a.img + (int64_t)b * C * HW;
         if (!BWD) {
             float *op = a.out + (int64_t)b * C * HW + pix;
-            for (int c = 0; c < C; ++c) op[c * HW] = blend(gather(sp + c * HW, s, W, H), s);
+            const TapAddr ta = tap_addr(s, W, H);
+            for (int c = 0; c < C; ++c) op[c * HW] = blend(gather(sp + c * HW, ta), s);
         } else {
             const float *go = a.grad_out + (int64_t)b * C * HW + pix;
             float gix = 0.f, giy = 0.f;
             const bool xin0 = (unsigned)s.x0 < (unsigned)W, xin1 = (unsigned)(s.x0 + 1) < (unsigned)W;
             const bool yin0 = (unsigned)s.y0 < (unsigned)H, yin1 = (unsigned)(s.y0 + 1) < (unsigned)H;
+            const TapAddr ta = tap_addr(s, W, H);
             for (int c = 0; c < C; ++c) {
-                const Taps t = gather(sp + c * HW, s, W, H);
+                const Taps t = gather(sp + c * HW, ta);
                 const float g = go[c * HW];
                 float dox, doy;
                 blend_grad(t, s, dox, doy);
@@ -728,6 +855,7 @@ int dispatch_mode(uint32_t flags, F &&f) {
 }
 
 inline dim3 pix_grid(int B, int H, int W) { return dim3((W + TX - 1) / TX, (H + TY - 1) / TY, B); }
+inline dim3 photo_grid(int B, int H, int W) { return dim3((W + TX - 1) / TX, (H + TY * RPT - 1) / (TY * RPT), B); }
 
 }  // namespace
 
@@ -736,7 +864,7 @@ extern "C" {
 int64_t dvf_pose_ws_floats(int V, int B) { return (int64_t)V * B * 12; }
 
 int64_t dvf_photo_partials_floats(int B, int H, int W, int V) {
-    const dim3 g = pix_grid(B, H, W);
+    const dim3 g = photo_grid(B, H, W);
     return (int64_t)g.x * g.y * g.z * V;
 }
 
@@ -808,9 +936,15 @@ int dvf_photo_loss_fwd(const float *tgt, const float *const *srcs, int V, const 
     if (!loss_out || !partials) return DVF_ERR_INVALID_ARG;
     a.partials = partials;
     hipStream_t st = dvf_stream(stream);
-    const dim3 grid = pix_grid(B, H, W);
+    const dim3 grid = photo_grid(B, H, W);
     rc = dispatch_mode(flags, [&](auto border, auto align) {
-        photo_fwd_kernel<decltype(border)::value, decltype(align)::value><<<grid, dim3(TX, TY), 0, st>>>(a);
+        constexpr bool BD = decltype(border)::value, AL = decltype(align)::value;
+        switch (V) {
+            case 1: photo_fwd_kernel<BD, AL, 1><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            case 2: photo_fwd_kernel<BD, AL, 2><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            case 3: photo_fwd_kernel<BD, AL, 3><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            default: photo_fwd_kernel<BD, AL, 4><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+        }
         DVF_LAUNCH_CHECK();
         return DVF_OK;
     });
@@ -836,8 +970,14 @@ int dvf_photo_loss_bwd(const float *tgt, const float *const *srcs, int V, const 
     hipStream_t st = dvf_stream(stream);
     if (g_pose && hipMemsetAsync(pose_ws, 0, sizeof(float) * 12 * V * B, st) != hipSuccess) return DVF_ERR_LAUNCH;
     rc = dispatch_mode(flags, [&](auto border, auto align) {
-        photo_bwd_kernel<decltype(border)::value, decltype(align)::value>
-            <<<pix_grid(B, H, W), dim3(TX, TY), 0, st>>>(a);
+        constexpr bool BD = decltype(border)::value, AL = decltype(align)::value;
+        const dim3 grid = photo_grid(B, H, W);
+        switch (V) {
+            case 1: photo_bwd_kernel<BD, AL, 1><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            case 2: photo_bwd_kernel<BD, AL, 2><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            case 3: photo_bwd_kernel<BD, AL, 3><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            default: photo_bwd_kernel<BD, AL, 4><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+        }
         DVF_LAUNCH_CHECK();
         return DVF_OK;
     });
