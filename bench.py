@@ -63,6 +63,18 @@ def build(args, device, world):
     return step, fwd_bwd, opt, ddp
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC summary (profiles/r01_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, read side corrected x2 as calibrated
+    there).  PMC passes cannot run inside the timed process, so the bench line quotes the committed measurement."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            k = json.load(f)["kernels"][kernel]
+        return (k["read_bytes_per_step"] + k["write_bytes_per_step"]) / k["launches_per_step"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def measure_kernels(step):
     """One eager step with HIP-event brackets around every C-ABI call (dvf.lib.KernelTimer)."""
     from dvf import lib as L
@@ -222,21 +234,24 @@ def main():
         ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         result["roofline"] = {"kernel": "conv_gather_kernel (Conv2d/ConvTranspose2d forward + dgrad)", "bound": "mfma",
                               "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "calls_per_step": g_calls,
+                              "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic("conv_gather"),
+                              "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_traffic.json)", "calls_per_step": g_calls,
                               "ms_per_step": g_ms}
         w = ks.get("conv_wgrad", {})
         if w.get("ms", 0) > 0:
             a = w["flops"] / (w["ms"] * 1e-3) / 1e12
             result["roofline_wgrad"] = {"kernel": "conv_wgrad_kernel", "bound": "mfma", "achieved": a,
                                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": a / PEAK_FP32_MFMA_TFLOPS,
-                                        "traffic": None, "calls_per_step": w["calls"], "ms_per_step": w["ms"]}
+                                        "traffic": pmc_traffic("conv_wgrad"), "calls_per_step": w["calls"], "ms_per_step": w["ms"]}
         p_ms = ks.get("photo_fwd", {}).get("ms", 0) + ks.get("photo_bwd", {}).get("ms", 0)
         p_by = ks.get("photo_fwd", {}).get("bytes", 0) + ks.get("photo_bwd", {}).get("bytes", 0)
         if p_ms > 0:
             a = p_by / (p_ms * 1e-3) / 1e9
             result["roofline_warp"] = {"kernel": "photo_fwd_kernel + photo_bwd_kernel (fused warp + photometric L1)",
                                        "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                       "frac": a / PEAK_HBM_GBPS, "traffic": None, "ms_per_step": p_ms}
+                                       "frac": a / PEAK_HBM_GBPS,
+                                       "traffic": (pmc_traffic("photo_fwd") or 0) + (pmc_traffic("photo_bwd") or 0) or None,
+                                       "algorithmic_bytes": p_by, "ms_per_step": p_ms}
         result["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(ks.items())}
     if world > 1:
         dist.barrier()
