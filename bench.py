@@ -53,6 +53,7 @@ def build(args, device, world):
         loss, terms = unsupervise_losses(disp_net, pose_net, batch)
         opt.zero_grad()
         loss.backward()
+        opt.join_wgrad()                # weight-gradient stream joins the main stream
         return (terms["total"], terms["img"], terms["smooth"])
 
     def step():

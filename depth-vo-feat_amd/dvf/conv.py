@@ -14,6 +14,14 @@ def _c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 def conv_out_size(h, k, stride, pad, opad, transposed):
     return (h - 1) * stride - 2 * pad + k + opad if transposed else (h + 2 * pad - k) // stride + 1
 
@@ -86,9 +94,13 @@ class ConvFn(torch.autograd.Function):
         if need_w:
             arena = ctx.wparam is not None
             dw = ctx.wparam._dvf_grad if arena else torch.empty_like(weight)
-            with L.timed("conv_wgrad", 2 * ctx.macs, tag=ctx.tag):
-                L.check(lib.dvf_conv2d_wgrad(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
-                                             L.dev(dpre), L.dev(dw), 1 if arena else 0, L.stream()), "dvf_conv2d_wgrad")
+            # with a FlatAdam arena the weight gradient is not consumed inside backward: run it on the side stream
+            side = ctx.wparam._dvf_owner.fork_wgrad(dpre, *inputs) if arena else None
+            with (torch.cuda.stream(side) if side is not None else _NullCtx()):
+                with L.timed("conv_wgrad", 2 * ctx.macs, tag=ctx.tag):
+                    L.check(lib.dvf_conv2d_wgrad(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
+                                                 L.dev(dpre), L.dev(dw), 1 if arena else 0, L.stream()),
+                            "dvf_conv2d_wgrad")
             if arena:
                 ctx.wparam._dvf_owner.grad_ready(ctx.wparam)
                 dw = None

@@ -22,11 +22,14 @@ class FlatAdam:
     """torch.optim.Adam over flat arenas.  ``params``: iterable of nn.Parameter (all nets together)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world_size=1,
-                 bucket_mb=25.0, process_group=None, overlap=True, always_reduce=False):
+                 bucket_mb=25.0, process_group=None, overlap=True, always_reduce=False, wgrad_stream=True):
         """overlap=True: buckets are all-reduced on a side stream from inside backward (eager execution).
         overlap=False: backward only marks gradients; ``step()`` all-reduces the buckets on the current stream --
         the mode used when forward+backward are replayed from a HIP graph.  always_reduce: run the exchange even
-        with world_size 1 (single-GPU rehearsal of the multi-GPU code path)."""
+        with world_size 1 (single-GPU rehearsal of the multi-GPU code path).
+        wgrad_stream: weight-gradient kernels run on a second HIP stream.  Nothing in backward consumes a weight
+        gradient, so they are off the critical path (dgrad chain) and fill the CUs that a single convolution kernel
+        leaves idle; the streams join in ``join_wgrad()`` (called by ``step()``)."""
         self.params = [p for p in params if p.requires_grad][::-1]       # backward-ready order
         if not self.params:
             raise ValueError("no parameters")
@@ -69,6 +72,28 @@ class FlatAdam:
         self._comm_stream = torch.cuda.Stream(device=dev) if (self.exchange and self.overlap and dev.type == "cuda") else None
         self._ranges = None
         self._reset_pending()
+        self.side = torch.cuda.Stream(device=dev) if (wgrad_stream and dev.type == "cuda") else None
+        self._side_dirty = False
+        self._keep = []          # tensors read by side-stream kernels, kept alive until the join
+
+    # ------------------------------------------------------------------ second stream for weight gradients
+    def fork_wgrad(self, *tensors):
+        """Make the side stream wait for everything enqueued so far on the current stream; returns the side stream
+        (or None: run on the current stream).  ``tensors`` are kept alive until ``join_wgrad``."""
+        if self.side is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.side.wait_event(ev)
+        self._keep.extend(t for t in tensors if t is not None)
+        self._side_dirty = True
+        return self.side
+
+    def join_wgrad(self):
+        if self._side_dirty:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._side_dirty = False
+        self._keep.clear()
 
     # ------------------------------------------------------------------ autograd side (called from ConvFn.backward)
     def _reset_pending(self):
@@ -99,10 +124,13 @@ class FlatAdam:
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self._comm_stream):
             self._comm_stream.wait_event(ev)
+            if self._side_dirty:
+                self._comm_stream.wait_stream(self.side)      # the bucket's weight gradients come from the side stream
             dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
 
     # ------------------------------------------------------------------ optimizer API
     def zero_grad(self):
+        self.join_wgrad()
         self.flat_g.zero_()
         self._reset_pending()
 
@@ -133,6 +161,7 @@ class FlatAdam:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
 
     def step(self):
+        self.join_wgrad()
         self.synchronize_grads()
         lib = L.lib()
         first = True

