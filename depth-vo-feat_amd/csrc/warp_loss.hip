@@ -32,9 +32,11 @@ __device__ __forceinline__ void mat3mul(const float *a, const float *b, float *o
             o[i * 3 + j] = a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j] + a[i * 3 + 2] * b[2 * 3 + j];
 }
 
-// pose (tx,ty,tz,rx,ry,rz) -> R.  euler: inverse_warp.py:77-114 (R = Rx @ Ry @ Rz); quat: :117-138.
-__device__ void pose_to_R(const float *p, bool quat, float *R) {
-    if (!quat) {
+// pose -> R.  mode 0 euler (tx,ty,tz,rx,ry,rz): inverse_warp.py:77-114 (R = Rx @ Ry @ Rz); mode 1 quat: :117-138;
+// mode 2 se3 (wx,wy,wz,ux,uy,uz): exponential map of se3_generate.py:13-43 / caffe/python/pygeometry.py:31-60
+// (R = I + sin(th)/th [w]x + 2 sin^2(th/2)/th^2 [w]x^2, first-order for th^2 < 1e-12).
+__device__ void pose_to_R(const float *p, int mode, float *R) {
+    if (mode == 0) {
         const float cx = cosf(p[3]), sx = sinf(p[3]);
         const float cy = cosf(p[4]), sy = sinf(p[4]);
         const float cz = cosf(p[5]), sz = sinf(p[5]);
@@ -44,7 +46,7 @@ __device__ void pose_to_R(const float *p, bool quat, float *R) {
         float XY[9];
         mat3mul(X, Y, XY);
         mat3mul(XY, Z, R);
-    } else {
+    } else if (mode == 1) {
         const float n = sqrtf(1.f + p[3] * p[3] + p[4] * p[4] + p[5] * p[5]);
         const float w = 1.f / n, x = p[3] / n, y = p[4] / n, z = p[5] / n;
         const float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
@@ -52,15 +54,35 @@ __device__ void pose_to_R(const float *p, bool quat, float *R) {
         R[0] = w2 + x2 - y2 - z2; R[1] = 2 * xy - 2 * wz;     R[2] = 2 * wy + 2 * xz;
         R[3] = 2 * wz + 2 * xy;   R[4] = w2 - x2 + y2 - z2;   R[5] = 2 * yz - 2 * wx;
         R[6] = 2 * xz - 2 * wy;   R[7] = 2 * wx + 2 * yz;     R[8] = w2 - x2 - y2 + z2;
+    } else {
+        const float wx = p[0], wy = p[1], wz = p[2];
+        const float Wx[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+        const float th2 = wx * wx + wy * wy + wz * wz;
+        float c1 = 1.f, c2 = 0.f;
+        if (th2 >= 1e-12f) {
+            const float th = sqrtf(th2), sh = sinf(0.5f * th);
+            c1 = sinf(th) / th;
+            c2 = 2.f * sh * sh / th2;
+        }
+        float W2[9];
+        mat3mul(Wx, Wx, W2);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) R[e] = ((e % 4 == 0) ? 1.f : 0.f) + c1 * Wx[e] + c2 * W2[e];
     }
 }
 
-__device__ void build_view(const float *pose6, const float *K, bool quat, ViewGeo *g) {
-    float R[9];
-    pose_to_R(pose6, quat, R);
+__device__ void build_view(const float *pose6, const float *K, int mode, ViewGeo *g) {
+    float R[9], t[3];
+    pose_to_R(pose6, mode, R);
+    if (mode == 2) {                                     // se3: t = R u   (se3_generate.py:47)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = R[i * 3 + 0] * pose6[3] + R[i * 3 + 1] * pose6[4] + R[i * 3 + 2] * pose6[5];
+    } else {
+        t[0] = pose6[0]; t[1] = pose6[1]; t[2] = pose6[2];
+    }
     mat3mul(K, R, g->A);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) g->tr[i] = K[i * 3 + 0] * pose6[0] + K[i * 3 + 1] * pose6[1] + K[i * 3 + 2] * pose6[2];
+    for (int i = 0; i < 3; ++i) g->tr[i] = K[i * 3 + 0] * t[0] + K[i * 3 + 1] * t[1] + K[i * 3 + 2] * t[2];
 }
 
 // Everything the sampler needs for one (pixel, view).
@@ -73,13 +95,31 @@ struct Samp {
     float wnw, wne, wsw, wse;
 };
 
-template <bool BORDER, bool ALIGN>
+template <bool BORDER, bool ALIGN, bool PIX = false>
 __device__ __forceinline__ Samp project(const ViewGeo &g, float cx, float cy, float cz, int W, int H) {
     Samp s;
     // p = (K R) cam + K t                                   inverse_warp.py:55-60
     const float px = g.A[0] * cx + g.A[1] * cy + g.A[2] * cz + g.tr[0];
     const float py = g.A[3] * cx + g.A[4] * cy + g.A[5] * cz + g.tr[1];
     const float pz = g.A[6] * cx + g.A[7] * cy + g.A[8] * cz + g.tr[2];
+    if (PIX) {
+        // pixel-coordinate front end (Caffe PinHole + InverseWarping semantics, pin_hole_layer.cu:10-50,
+        // inverse_warping_layer.cu:10-52): u = fx X / (Z + 1e-12) + cx sampled directly, each tap bounds-checked
+        s.zpass = true;
+        s.Z = pz + 1e-12f;
+        s.xq = px / s.Z;
+        s.yq = py / s.Z;
+        s.ix = s.xq;
+        s.iy = s.yq;
+        s.dix = 1.f;
+        s.diy = 1.f;
+        const float fx = floorf(s.ix), fy = floorf(s.iy);
+        s.x0 = (fx >= -2.f && fx <= (float)W + 1.f) ? (int)fx : -4;
+        s.y0 = (fy >= -2.f && fy <= (float)H + 1.f) ? (int)fy : -4;
+        const float ex = (fx + 1.f) - s.ix, ey = (fy + 1.f) - s.iy, dx = s.ix - fx, dy = s.iy - fy;
+        s.wnw = ex * ey; s.wne = dx * ey; s.wsw = ex * dy; s.wse = dx * dy;
+        return s;
+    }
     s.zpass = pz >= 1e-3f;
     s.Z = fmaxf(pz, 1e-3f);                                 // :63
     s.xq = px / s.Z;
@@ -184,13 +224,13 @@ struct PhotoArgs {
 };
 
 __device__ __forceinline__ void block_setup(const PhotoArgs &a, int b, int tid, ViewGeo *geo, float *kinv, float *kmat) {
-    if (tid < a.V) build_view(a.pose + ((int64_t)tid * a.B + b) * 6, a.K + (int64_t)b * 9, a.quat != 0, &geo[tid]);
+    if (tid < a.V) build_view(a.pose + ((int64_t)tid * a.B + b) * 6, a.K + (int64_t)b * 9, (int)a.quat, &geo[tid]);
     if (tid >= 64 && tid < 73) kinv[tid - 64] = a.Kinv[(int64_t)b * 9 + tid - 64];
     if (kmat && tid >= 128 && tid < 137) kmat[tid - 128] = a.K[(int64_t)b * 9 + tid - 128];
     __syncthreads();
 }
 
-template <bool BORDER, bool ALIGN, int NV>
+template <bool BORDER, bool ALIGN, bool PIX, int NV>
 __global__ __launch_bounds__(256) void photo_fwd_kernel(PhotoArgs a) {
     __shared__ ViewGeo geo[DVF_MAX_VIEWS];
     __shared__ float kinv[9];
@@ -222,7 +262,7 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(PhotoArgs a) {
         bool nz[NV];
 #pragma unroll
         for (int vi = 0; vi < NV; ++vi) {
-            s[vi] = project<BORDER, ALIGN>(geo[vi], cx, cy, cz, W, H);
+            s[vi] = project<BORDER, ALIGN, PIX>(geo[vi], cx, cy, cz, W, H);
             ta[vi] = tap_addr(s[vi], W, H);
             acc[vi] = 0.f;
             nz[vi] = false;
@@ -357,7 +397,7 @@ __device__ __forceinline__ void reduce_pose_partials(float (&acc)[NV][12], int V
     }
 }
 
-template <bool BORDER, bool ALIGN, int NV>
+template <bool BORDER, bool ALIGN, bool PIX, int NV>
 __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
     __shared__ ViewGeo geo[DVF_MAX_VIEWS];
     __shared__ float kinv[9], kmat[9];
@@ -393,7 +433,7 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
         bool nzv[NV];
 #pragma unroll
         for (int vi = 0; vi < NV; ++vi) {
-            sv[vi] = project<BORDER, ALIGN>(geo[vi], cx, cy, cz, W, H);
+            sv[vi] = project<BORDER, ALIGN, PIX>(geo[vi], cx, cy, cz, W, H);
             tav[vi] = tap_addr(sv[vi], W, H);
             gixv[vi] = giyv[vi] = absumv[vi] = 0.f;
             nzv[vi] = false;
@@ -493,6 +533,43 @@ __global__ void pose_finalize_kernel(const float *pose, const float *ws, float *
     const float *g = ws + (int64_t)i * 12;
     const float *gR = g + 3;
     float *o = g_pose + (int64_t)i * 6;
+    if (quat == 2) {
+        // se3 (w, u): y = R x + R u.  g_u = R^T g_t;  dL/dR += g_t (x) u;  dL/dw_i = <dL/dR, dR/dw_i> with
+        // dR/dw_i = (w_i [w]x + [w x (I - R) e_i]x) / th^2 * R   (se3_generate.py:57-100)
+        float R[9];
+        pose_to_R(p, 2, R);
+        const float gt[3] = {g[0], g[1], g[2]};
+        const float u[3] = {p[3], p[4], p[5]}, w[3] = {p[0], p[1], p[2]};
+        float GR[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) GR[i * 3 + j] = gR[i * 3 + j] + gt[i] * u[j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o[3 + j] = R[0 * 3 + j] * gt[0] + R[1 * 3 + j] * gt[1] + R[2 * 3 + j] * gt[2];
+        const float th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+        const float Wx[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+        for (int i = 0; i < 3; ++i) {
+            float D[9];
+            if (th2 < 1e-12f) {
+                const float G[3][9] = {{0, 0, 0, 0, 0, 1, 0, -1, 0}, {0, 0, -1, 0, 0, 0, 1, 0, 0}, {0, 1, 0, -1, 0, 0, 0, 0, 0}};
+                for (int e = 0; e < 9; ++e) D[e] = G[i][e];       // generators exactly as the reference writes them
+            } else {
+                // v = (I - R) e_i ; c = w x v
+                const float v[3] = {(i == 0 ? 1.f : 0.f) - R[0 * 3 + i], (i == 1 ? 1.f : 0.f) - R[1 * 3 + i],
+                                    (i == 2 ? 1.f : 0.f) - R[2 * 3 + i]};
+                const float cx = w[1] * v[2] - w[2] * v[1], cy = w[2] * v[0] - w[0] * v[2], cz = w[0] * v[1] - w[1] * v[0];
+                const float Cx[9] = {0, -cz, cy, cz, 0, -cx, -cy, cx, 0};
+                float M[9];
+                for (int e = 0; e < 9; ++e) M[e] = (w[i] * Wx[e] + Cx[e]) / th2;
+                mat3mul(M, R, D);
+            }
+            float sacc = 0.f;
+            for (int e = 0; e < 9; ++e) sacc += GR[e] * D[e];
+            o[i] = sacc;
+        }
+        return;
+    }
     o[0] = g[0]; o[1] = g[1]; o[2] = g[2];
     if (!quat) {
         const float cx = cosf(p[3]), sx = sinf(p[3]);
@@ -542,13 +619,13 @@ struct WarpArgs {
     uint32_t quat;
 };
 
-template <bool BORDER, bool ALIGN, bool BWD>
+template <bool BORDER, bool ALIGN, bool PIX, bool BWD>
 __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
     __shared__ ViewGeo geo;
     __shared__ float kinv[9], kmat[9];
     __shared__ float red[TY][DVF_MAX_VIEWS * 12];
     const int b = blockIdx.z, tid = threadIdx.y * TX + threadIdx.x;
-    if (tid == 0) build_view(a.pose + (int64_t)b * 6, a.K + (int64_t)b * 9, a.quat != 0, &geo);
+    if (tid == 0) build_view(a.pose + (int64_t)b * 6, a.K + (int64_t)b * 9, (int)a.quat, &geo);
     if (tid >= 64 && tid < 73) kinv[tid - 64] = a.Kinv[(int64_t)b * 9 + tid - 64];
     if (tid >= 128 && tid < 137) kmat[tid - 128] = a.K[(int64_t)b * 9 + tid - 128];
     __syncthreads();
@@ -566,7 +643,7 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
         const float c0y = kinv[3] * u + kinv[4] * v + kinv[5];
         const float c0z = kinv[6] * u + kinv[7] * v + kinv[8];
         const float cx = c0x * d, cy = c0y * d, cz = c0z * d;
-        const Samp s = project<BORDER, ALIGN>(geo, cx, cy, cz, W, H);
+        const Samp s = project<BORDER, ALIGN, PIX>(geo, cx, cy, cz, W, H);
         const float *sp = a.img + (int64_t)b * C * HW;
         if (!BWD) {
             float *op = a.out + (int64_t)b * C * HW + pix;
@@ -720,12 +797,13 @@ __global__ void pose_vec2mat_kernel(const float *pose, float *out, int n, uint32
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float R[9];
-    pose_to_R(pose + (int64_t)i * 6, quat != 0, R);
+    pose_to_R(pose + (int64_t)i * 6, (int)quat, R);
     float *o = out + (int64_t)i * 12;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         o[r * 4 + 0] = R[r * 3 + 0]; o[r * 4 + 1] = R[r * 3 + 1]; o[r * 4 + 2] = R[r * 3 + 2];
-        o[r * 4 + 3] = pose[(int64_t)i * 6 + r];
+        const float *p = pose + (int64_t)i * 6;
+        o[r * 4 + 3] = quat == 2 ? R[r * 3 + 0] * p[3] + R[r * 3 + 1] * p[4] + R[r * 3 + 2] * p[5] : p[r];   // se3: t = R u
     }
 }
 
@@ -847,12 +925,17 @@ __global__ __launch_bounds__(256) void cam2pixel_bwd_kernel(const float *cam, co
 
 template <typename F>
 int dispatch_mode(uint32_t flags, F &&f) {
+    using T = std::integral_constant<bool, true>;
+    using N = std::integral_constant<bool, false>;
+    if (flags & DVF_PIXEL_COORDS) return f(N{}, N{}, T{});
     const bool border = flags & DVF_PAD_BORDER, align = flags & DVF_ALIGN_CORNERS;
-    if (border && align) return f(std::integral_constant<bool, true>{}, std::integral_constant<bool, true>{});
-    if (border) return f(std::integral_constant<bool, true>{}, std::integral_constant<bool, false>{});
-    if (align) return f(std::integral_constant<bool, false>{}, std::integral_constant<bool, true>{});
-    return f(std::integral_constant<bool, false>{}, std::integral_constant<bool, false>{});
+    if (border && align) return f(T{}, T{}, N{});
+    if (border) return f(T{}, N{}, N{});
+    if (align) return f(N{}, T{}, N{});
+    return f(N{}, N{}, N{});
 }
+
+inline uint32_t rot_mode(uint32_t flags) { return (flags & DVF_POSE_SE3) ? 2u : ((flags & DVF_ROT_QUAT) ? 1u : 0u); }
 
 inline dim3 pix_grid(int B, int H, int W) { return dim3((W + TX - 1) / TX, (H + TY - 1) / TY, B); }
 inline dim3 photo_grid(int B, int H, int W) { return dim3((W + TX - 1) / TX, (H + TY * RPT - 1) / (TY * RPT), B); }
@@ -876,9 +959,9 @@ int dvf_inverse_warp_fwd(const float *img, const float *depth, const float *pose
                          float *out, int B, int C, int H, int W, uint32_t flags, void *stream) {
     if (!img || !depth || !pose || !K || !Kinv || !out || B <= 0 || C <= 0 || H < 2 || W < 2 || B > 65535)
         return DVF_ERR_INVALID_ARG;
-    WarpArgs a{img, depth, pose, K, Kinv, nullptr, out, nullptr, nullptr, nullptr, B, C, H, W, flags & DVF_ROT_QUAT};
-    return dispatch_mode(flags, [&](auto border, auto align) {
-        warp_kernel<decltype(border)::value, decltype(align)::value, false>
+    WarpArgs a{img, depth, pose, K, Kinv, nullptr, out, nullptr, nullptr, nullptr, B, C, H, W, rot_mode(flags)};
+    return dispatch_mode(flags, [&](auto border, auto align, auto pix) {
+        warp_kernel<decltype(border)::value, decltype(align)::value, decltype(pix)::value, false>
             <<<pix_grid(B, H, W), dim3(TX, TY), 0, dvf_stream(stream)>>>(a);
         DVF_LAUNCH_CHECK();
         return DVF_OK;
@@ -894,16 +977,16 @@ int dvf_inverse_warp_bwd(const float *img, const float *depth, const float *pose
     hipStream_t st = dvf_stream(stream);
     if (g_pose && hipMemsetAsync(pose_ws, 0, sizeof(float) * 12 * B, st) != hipSuccess) return DVF_ERR_LAUNCH;
     WarpArgs a{img, depth, pose, K, Kinv, grad_out, nullptr, g_img, g_depth, g_pose ? pose_ws : nullptr,
-               B, C, H, W, flags & DVF_ROT_QUAT};
-    const int rc = dispatch_mode(flags, [&](auto border, auto align) {
-        warp_kernel<decltype(border)::value, decltype(align)::value, true>
+               B, C, H, W, rot_mode(flags)};
+    const int rc = dispatch_mode(flags, [&](auto border, auto align, auto pix) {
+        warp_kernel<decltype(border)::value, decltype(align)::value, decltype(pix)::value, true>
             <<<pix_grid(B, H, W), dim3(TX, TY), 0, st>>>(a);
         DVF_LAUNCH_CHECK();
         return DVF_OK;
     });
     if (rc != DVF_OK) return rc;
     if (g_pose) {
-        pose_finalize_kernel<<<(B + 63) / 64, 64, 0, st>>>(pose, pose_ws, g_pose, B, flags & DVF_ROT_QUAT);
+        pose_finalize_kernel<<<(B + 63) / 64, 64, 0, st>>>(pose, pose_ws, g_pose, B, rot_mode(flags));
         DVF_LAUNCH_CHECK();
     }
     return DVF_OK;
@@ -923,7 +1006,7 @@ static int fill_photo_args(PhotoArgs &a, const float *tgt, const float *const *s
     }
     a.depth = depth; a.pose = pose; a.K = K; a.Kinv = Kinv; a.mask = mask;
     a.B = B; a.C = C; a.H = H; a.W = W; a.V = V;
-    a.quat = flags & DVF_ROT_QUAT;
+    a.quat = rot_mode(flags);
     return DVF_OK;
 }
 
@@ -937,13 +1020,13 @@ int dvf_photo_loss_fwd(const float *tgt, const float *const *srcs, int V, const 
     a.partials = partials;
     hipStream_t st = dvf_stream(stream);
     const dim3 grid = photo_grid(B, H, W);
-    rc = dispatch_mode(flags, [&](auto border, auto align) {
-        constexpr bool BD = decltype(border)::value, AL = decltype(align)::value;
+    rc = dispatch_mode(flags, [&](auto border, auto align, auto pix) {
+        constexpr bool BD = decltype(border)::value, AL = decltype(align)::value, PX = decltype(pix)::value;
         switch (V) {
-            case 1: photo_fwd_kernel<BD, AL, 1><<<grid, dim3(TX, TY), 0, st>>>(a); break;
-            case 2: photo_fwd_kernel<BD, AL, 2><<<grid, dim3(TX, TY), 0, st>>>(a); break;
-            case 3: photo_fwd_kernel<BD, AL, 3><<<grid, dim3(TX, TY), 0, st>>>(a); break;
-            default: photo_fwd_kernel<BD, AL, 4><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            case 1: photo_fwd_kernel<BD, AL, PX, 1><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            case 2: photo_fwd_kernel<BD, AL, PX, 2><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            case 3: photo_fwd_kernel<BD, AL, PX, 3><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            default: photo_fwd_kernel<BD, AL, PX, 4><<<grid, dim3(TX, TY), 0, st>>>(a); break;
         }
         DVF_LAUNCH_CHECK();
         return DVF_OK;
@@ -969,21 +1052,21 @@ int dvf_photo_loss_bwd(const float *tgt, const float *const *srcs, int V, const 
     for (int v = 0; v < V; ++v) a.g_src[v] = g_srcs ? g_srcs[v] : nullptr;
     hipStream_t st = dvf_stream(stream);
     if (g_pose && hipMemsetAsync(pose_ws, 0, sizeof(float) * 12 * V * B, st) != hipSuccess) return DVF_ERR_LAUNCH;
-    rc = dispatch_mode(flags, [&](auto border, auto align) {
-        constexpr bool BD = decltype(border)::value, AL = decltype(align)::value;
+    rc = dispatch_mode(flags, [&](auto border, auto align, auto pix) {
+        constexpr bool BD = decltype(border)::value, AL = decltype(align)::value, PX = decltype(pix)::value;
         const dim3 grid = photo_grid(B, H, W);
         switch (V) {
-            case 1: photo_bwd_kernel<BD, AL, 1><<<grid, dim3(TX, TY), 0, st>>>(a); break;
-            case 2: photo_bwd_kernel<BD, AL, 2><<<grid, dim3(TX, TY), 0, st>>>(a); break;
-            case 3: photo_bwd_kernel<BD, AL, 3><<<grid, dim3(TX, TY), 0, st>>>(a); break;
-            default: photo_bwd_kernel<BD, AL, 4><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            case 1: photo_bwd_kernel<BD, AL, PX, 1><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            case 2: photo_bwd_kernel<BD, AL, PX, 2><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            case 3: photo_bwd_kernel<BD, AL, PX, 3><<<grid, dim3(TX, TY), 0, st>>>(a); break;
+            default: photo_bwd_kernel<BD, AL, PX, 4><<<grid, dim3(TX, TY), 0, st>>>(a); break;
         }
         DVF_LAUNCH_CHECK();
         return DVF_OK;
     });
     if (rc != DVF_OK) return rc;
     if (g_pose) {
-        pose_finalize_kernel<<<(V * B + 63) / 64, 64, 0, st>>>(pose, pose_ws, g_pose, V * B, flags & DVF_ROT_QUAT);
+        pose_finalize_kernel<<<(V * B + 63) / 64, 64, 0, st>>>(pose, pose_ws, g_pose, V * B, rot_mode(flags));
         DVF_LAUNCH_CHECK();
     }
     return DVF_OK;
@@ -991,7 +1074,7 @@ int dvf_photo_loss_bwd(const float *tgt, const float *const *srcs, int V, const 
 
 int dvf_pose_vec2mat_fwd(const float *pose, float *out, int n, uint32_t flags, void *stream) {
     if (!pose || !out || n <= 0) return DVF_ERR_INVALID_ARG;
-    pose_vec2mat_kernel<<<(n + 63) / 64, 64, 0, dvf_stream(stream)>>>(pose, out, n, flags & DVF_ROT_QUAT);
+    pose_vec2mat_kernel<<<(n + 63) / 64, 64, 0, dvf_stream(stream)>>>(pose, out, n, rot_mode(flags));
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }
@@ -1002,7 +1085,7 @@ int dvf_pose_vec2mat_bwd(const float *pose, const float *g_mat, float *g_pose, f
     hipStream_t st = dvf_stream(stream);
     mat_grad_to_ws_kernel<<<(n + 63) / 64, 64, 0, st>>>(g_mat, ws, n);
     DVF_LAUNCH_CHECK();
-    pose_finalize_kernel<<<(n + 63) / 64, 64, 0, st>>>(pose, ws, g_pose, n, flags & DVF_ROT_QUAT);
+    pose_finalize_kernel<<<(n + 63) / 64, 64, 0, st>>>(pose, ws, g_pose, n, rot_mode(flags));
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }

@@ -31,7 +31,7 @@ class ConvDesc(ctypes.Structure):
 c_desc = ctypes.POINTER(ConvDesc)
 c_ip = ctypes.POINTER(ctypes.c_int)
 
-ROT_QUAT, PAD_BORDER, ALIGN_CORNERS = 1, 2, 4
+ROT_QUAT, PAD_BORDER, ALIGN_CORNERS, POSE_SE3, PIXEL_COORDS = 1, 2, 4, 8, 16
 ACT_NONE, ACT_RELU, ACT_SIGMOID_AFFINE = 0, 1, 2
 MAX_VIEWS, MAX_SEGS = 4, 3
 

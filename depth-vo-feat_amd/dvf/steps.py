@@ -53,3 +53,23 @@ def train_sfm_losses(disp_net, pose_exp_net, batch, w1=1.0, w2=0.0, w3=0.1, smoo
         terms["exp"] = l2.detach()
     terms["total"] = loss.detach()
     return loss, terms
+
+
+def unsupervise_dvo_losses(depth_net, pose_net, batch, img_scale=0.004, smooth_weight=10.0, depth_eps=1e-4):
+    """unsupervise_dvo.py:83-122 (the Caffe-style chain): T = (T_R2L, T_2to1) as se(3) vectors -> exponential map
+    (t = R u) -> GeoTransform -> PinHole -> InverseWarping in PIXEL coordinates -> exact-zero-masked L1 for the
+    stereo (L2 -> R2) and temporal (R1 -> R2) warps + 10 * smooth(depth).  All of it is the fused warp kernel with the
+    DVF_POSE_SE3 | DVF_PIXEL_COORDS front end.  batch["T_R2L"] must be in the se(3) order (w, u), i.e. (0,0,0,Tx,0,0)
+    as the reference dataset writes it (data/dataset_builder.py:155)."""
+    from dvf import lib as L
+    from dvf.ops import PhotoLossFn
+    R2, R1, L2 = batch["img_R2"], batch["img_R1"], batch["img_L2"]
+    inv_depth = depth_net(R2)[0]
+    _, T_2to1 = pose_net((R2, R1))
+    depth = reciprocal(inv_depth, depth_eps)                               # [B,1,H,W]
+    pose = torch.stack((batch["T_R2L"], T_2to1), dim=0)                    # [V=2,B,6]: view 0 = left image, view 1 = R1
+    photo = PhotoLossFn.apply(img_scale * R2, depth.squeeze(1), pose, batch["K"], batch["Kinv"], None,
+                              L.POSE_SE3 | L.PIXEL_COORDS, img_scale * L2, img_scale * R1)
+    smooth = LF.smooth_loss(depth)
+    loss = photo + smooth_weight * smooth
+    return loss, {"photo": photo.detach(), "smooth": smooth.detach(), "total": loss.detach()}

@@ -34,6 +34,11 @@ extern "C" {
 #define DVF_ROT_QUAT 1u      /* pose[3:6] are the last 3 quaternion coefficients (inverse_warp.py:117-138); default euler (:77-114) */
 #define DVF_PAD_BORDER 2u    /* padding_mode='border'; default 'zeros' incl. the coords-set-to-2 overwrite (inverse_warp.py:67-71) */
 #define DVF_ALIGN_CORNERS 4u /* grid_sample(align_corners=True); default False = what the reference runs as (SURVEY.md preamble #5) */
+#define DVF_POSE_SE3 8u      /* pose = (wx,wy,wz,ux,uy,uz): exponential map with t = R u (se3_generate.py:7-53, caffe/python/pygeometry.py:6-114);
+                                the front end of unsupervise_dvo.py:98-100 */
+#define DVF_PIXEL_COORDS 16u /* sample at pixel coordinates u = fx X/(Z+1e-12) + cx, taps bounds-checked individually, no coords
+                                overwrite and no depth clamp: Caffe GeoTransform -> PinHole -> InverseWarping semantics
+                                (geometry_transformation.cu:10-47, pin_hole_layer.cu:10-50, inverse_warping_layer.cu:10-52) */
 
 /* activation codes for the convolution epilogues */
 #define DVF_ACT_NONE 0

@@ -127,3 +127,95 @@ def inverse_warp(img, depth, pose, intrinsics, intrinsics_inv, rotation_mode="eu
     proj = intrinsics @ pose_vec2mat(pose, rotation_mode)
     grid = cam2pixel(cam, proj[:, :, :3], proj[:, :, -1:], padding_mode)
     return bilinear_sample(img, grid, padding_mode, align_corners)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# unsupervise_dvo.py front end (Caffe-style chain).  The Python port in the reference (geo_transform.py) is dead code
+# (exit(0) at :31), so these restate the Caffe layers it was ported from; only the SE3 exponential map has a runnable
+# Python twin (se3_generate.py) and golden vectors (tests/golden/se3_expmap.npz).  The pixel-coordinate sampling
+# itself is "parity unpinned": it is cross-checked against the align_corners=True grid path instead.
+
+class _Se3Exp(torch.autograd.Function):
+    """Forward AND hand-written backward of the reference's SE3_Generator_KITTI (se3_generate.py:7-103), restated
+    with batched torch ops.  The backward is the reference's, not autograd's: for th^2 < 1e-12 it uses the constant
+    "generators" exactly as the reference writes them (se3_generate.py:75-78), whose sign is the opposite of
+    d(I + [w]x)/dw -- a quirk of the reference that the parity target keeps."""
+
+    @staticmethod
+    def forward(ctx, vec):
+        w, u = vec[:, :3], vec[:, 3:]
+        z = torch.zeros_like(w[:, 0])
+        wx = torch.stack([z, -w[:, 2], w[:, 1], w[:, 2], z, -w[:, 0], -w[:, 1], w[:, 0], z], dim=1).reshape(-1, 3, 3)
+        th2 = (w * w).sum(1)
+        small = th2 < 1e-12                                                # se3_generate.py:11,33
+        th = torch.sqrt(torch.where(small, torch.ones_like(th2), th2))
+        c1 = torch.where(small, torch.ones_like(th), torch.sin(th) / th)   # :37
+        c2 = torch.where(small, torch.zeros_like(th), 2 * torch.sin(th / 2) ** 2 / th ** 2)   # :38
+        eye = torch.eye(3, dtype=vec.dtype).expand_as(wx)
+        R = eye + c1.view(-1, 1, 1) * wx + c2.view(-1, 1, 1) * (wx @ wx)    # :34,42
+        ctx.save_for_backward(w, u, wx, R, th2)
+        return torch.cat([R, R @ u.unsqueeze(-1)], dim=2)                  # :45-47
+
+    @staticmethod
+    def backward(ctx, g):
+        w, u, wx, R, th2 = ctx.saved_tensors
+        gT, gR = g[:, :, 3], g[:, :, :3]
+        g_u = (gT.unsqueeze(1) @ R).squeeze(1)                              # dLdut = dLdT x R, :64
+        gR = gR + gT.unsqueeze(2) * u.unsqueeze(1)                          # grad_corr, :67-71
+        gens = torch.tensor([[[0, 0, 0], [0, 0, 1], [0, -1, 0]], [[0, 0, -1], [0, 0, 0], [1, 0, 0]],
+                             [[0, 1, 0], [-1, 0, 0], [0, 0, 0]]], dtype=g.dtype)   # :75-78
+        eye = torch.eye(3, dtype=g.dtype)
+        small = th2 < 1e-12
+        g_w = []
+        for i in range(3):
+            cross_term = (wx @ (eye - R)[:, :, i:i + 1]).squeeze(-1)       # uw_x (I - R) e_i, :85
+            z = torch.zeros_like(cross_term[:, 0])
+            cross = torch.stack([z, -cross_term[:, 2], cross_term[:, 1], cross_term[:, 2], z, -cross_term[:, 0],
+                                 -cross_term[:, 1], cross_term[:, 0], z], dim=1).reshape(-1, 3, 3)   # :86-92
+            safe = torch.where(small, torch.ones_like(th2), th2)
+            dR = ((w[:, i].view(-1, 1, 1) * wx + cross) / safe.view(-1, 1, 1)) @ R                 # :98
+            dR = torch.where(small.view(-1, 1, 1), gens[i].expand_as(dR), dR)                      # :96
+            g_w.append((gR * dR).sum((1, 2)))                                                      # :99
+        return torch.cat([torch.stack(g_w, dim=1), g_u], dim=1)
+
+
+def se3_exp(vec):
+    """(wx,wy,wz,ux,uy,uz) [B,6] -> [R | R u] [B,3,4] with the reference's own backward (see _Se3Exp)."""
+    return _Se3Exp.apply(vec)
+
+
+def inverse_warp_pixel(img, depth, T, K):
+    """Caffe GeoTransform -> PinHole -> InverseWarping (geometry_transformation.cu:10-47, pin_hole_layer.cu:10-50,
+    inverse_warping_layer.cu:10-52): X = (x-cx)/fx d, Y = (y-cy)/fy d; p = T [X,Y,d,1]; u = fx px/(pz+1e-12) + cx,
+    v likewise; bilinear gather at (u, v) in PIXEL units, each of the 4 taps bounds-checked (out-of-bounds taps add 0).
+    img [B,C,H,W], depth [B,H,W], T [B,3,4], K [B,3,3] (fx, fy, cx, cy read from it)."""
+    b, c, h, w = img.shape
+    fx, fy, cx, cy = K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=img.dtype), torch.arange(w, dtype=img.dtype), indexing="ij")
+    X = (xs[None] - cx.view(-1, 1, 1)) / fx.view(-1, 1, 1) * depth
+    Y = (ys[None] - cy.view(-1, 1, 1)) / fy.view(-1, 1, 1) * depth
+    pts = torch.stack([X, Y, depth, torch.ones_like(depth)], dim=1).reshape(b, 4, -1)
+    p = (T @ pts).reshape(b, 3, h, w)
+    u = fx.view(-1, 1, 1) * p[:, 0] / (p[:, 2] + 1e-12) + cx.view(-1, 1, 1)
+    v = fy.view(-1, 1, 1) * p[:, 1] / (p[:, 2] + 1e-12) + cy.view(-1, 1, 1)
+    x0, y0 = torch.floor(u), torch.floor(v)
+    flat = img.reshape(b, c, h * w)
+    out = 0
+    for dx, dy in ((0, 0), (1, 0), (0, 1), (1, 1)):                 # nw, ne, sw, se
+        xi, yi = x0 + dx, y0 + dy
+        wt = (1 - (u - xi).abs()) * (1 - (v - yi).abs())
+        ok = (xi >= 0) & (xi <= w - 1) & (yi >= 0) & (yi <= h - 1)
+        idx = (yi.clamp(0, h - 1) * w + xi.clamp(0, w - 1)).long().reshape(b, 1, -1).expand(b, c, -1)
+        out = out + torch.gather(flat, 2, idx).reshape(b, c, h, w) * (wt * ok.to(img.dtype)).unsqueeze(1)
+    return out
+
+
+def dvo_photometric_loss(img_R2, img_L2, img_R1, depth, T_R2L, T_2to1, K):
+    """LR_error + R12_error of unsupervise_dvo.py:96-117: se3 exp-map poses, pixel-coordinate warps of the left image
+    (stereo pose) and of the previous right image (temporal pose), exact-zero mask, L1 mean each."""
+    loss = 0
+    for src, pose in ((img_L2, T_R2L), (img_R1, T_2to1)):
+        warped = inverse_warp_pixel(src, depth, se3_exp(pose), K)
+        valid = 1 - (warped == 0).prod(1, keepdim=True).type_as(warped)
+        loss = loss + ((img_R2 - warped) * valid).abs().mean()
+    return loss

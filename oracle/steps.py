@@ -66,17 +66,24 @@ def _leaf(sd):
 
 def step_unsupervise(disp_sd, pose_sd, batch, adam_state=None, lr=1e-3, weight_decay=1e-8,
                      img_scale=0.004, smooth_weight=10.0, feat_sd=None, feat_weight=0.1,
-                     do_update=True):
-    """One unsupervise.py iteration.  Returns dict(losses, grads) and updates the dicts in place."""
+                     do_update=True, dvo=False):
+    """One unsupervise.py iteration.  Returns dict(losses, grads) and updates the dicts in place.  dvo=True swaps the
+    image term for the unsupervise_dvo.py chain (se3 exponential map + pixel-coordinate warp, batch["T_R2L"] then in
+    (w, u) order)."""
     dsd, psd = _leaf(disp_sd), _leaf(pose_sd)
     fsd = _leaf(feat_sd) if feat_sd is not None else None
     R2, R1, L2 = batch["img_R2"], batch["img_R1"], batch["img_L2"]
     disp = nets.dispnet_forward(dsd, R2)[0]                                   # unsupervise.py:94
     _, T_2to1 = nets.posenet_forward(psd, torch.cat((R2, R1), 1), 2, True, sfm=False)   # :92,95
     depth = (1 / (disp + 1e-4)).squeeze(1)                                    # :99
-    img_loss = losses.photometric_reconstruction_loss(img_scale * R2, img_scale * R1, img_scale * L2,
-                                                      depth, T_2to1, batch["T_R2L"], batch["K"],
-                                                      batch["Kinv"])          # :101
+    if dvo:
+        from . import geometry
+        img_loss = geometry.dvo_photometric_loss(img_scale * R2, img_scale * L2, img_scale * R1, depth,
+                                                 batch["T_R2L"], T_2to1, batch["K"])   # unsupervise_dvo.py:96-117
+    else:
+        img_loss = losses.photometric_reconstruction_loss(img_scale * R2, img_scale * R1, img_scale * L2,
+                                                          depth, T_2to1, batch["T_R2L"], batch["K"],
+                                                          batch["Kinv"])      # :101
     smooth = losses.smooth_loss(depth.unsqueeze(1))                           # :102
     total = img_loss + smooth_weight * smooth
     out = {"img": img_loss.detach(), "smooth": smooth.detach()}

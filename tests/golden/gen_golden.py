@@ -314,6 +314,22 @@ def gen_steps():
     save("step_train_sfm", **rec, b=b, h=h, w=w)
 
 
+def gen_se3():
+    """SE3 exponential map forward/backward from the reference's se3_generate.py (numpy on CPU; its forward and
+    backward end in .cuda(), which is an identity in this CPU-only generator process)."""
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import se3_generate as ref_se3
+    g = torch.Generator().manual_seed(31)
+    vec = torch.randn(6, 6, generator=g, dtype=torch.float64) * 0.3
+    vec[0, :3] = 0.0                      # theta = 0: the first-order branch
+    vec[1, :3] *= 1e-8
+    x = vec.float().view(6, 6, 1, 1).requires_grad_(True)
+    out = ref_se3.generate_se3(x)         # [6,1,4,4] float64
+    wt = torch.randn(6, 1, 4, 4, generator=g, dtype=torch.float64)
+    (out * wt).sum().backward()
+    save("se3_expmap", vec=_np(vec.float()), out=_np(out), wt=_np(wt), g_vec=_np(x.grad.view(6, 6)))
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference not present: golden vectors can only be generated in the build container")
@@ -326,6 +342,7 @@ def main():
         gen_losses()
         gen_nets()
         gen_steps()
+        gen_se3()
 
 
 if __name__ == "__main__":

@@ -237,3 +237,44 @@ def test_geometry_helpers_vs_oracle(rot):
             assert rel_err(a.grad, r.grad) < TOL, (pad, nm)
     iw.set_id_grid(depth.to(DEV))
     assert rel_err(iw.pixel_coords, og.pixel_grid(h, w, torch.float32)) == 0.0
+
+
+def test_se3_expmap_golden():
+    """generate_se3 (forward + the reference's hand-written backward, incl. the theta -> 0 branch) vs vectors from
+    the reference's se3_generate.py."""
+    import se3_generate
+    g = load_golden("se3_expmap")
+    vec = t(g["vec"], DEV).view(-1, 6, 1, 1).requires_grad_(True)
+    out = se3_generate.generate_se3(vec)
+    assert tuple(out.shape) == (6, 1, 4, 4)
+    assert rel_err(out, g["out"]) < 1e-5
+    (out * t(g["wt"], DEV).float()).sum().backward()
+    assert rel_err(vec.grad.view(6, 6), g["g_vec"]) < TOL
+
+
+def test_dvo_front_end_vs_oracle():
+    """DVF_POSE_SE3 | DVF_PIXEL_COORDS front end (unsupervise_dvo.py chain) vs the oracle's restatement of the Caffe
+    layers.  Sources are linear ramps (no gradient discontinuity at tap-set crossings), the target is noise."""
+    from dvf.ops import PhotoLossFn
+    from dvf import lib as L
+    b, h, w = 2, 40, 72
+    gen = torch.Generator().manual_seed(41)
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    ramp = lambda a_, b_, c_: a_ * xx + b_ * yy + c_
+    L2 = torch.stack((ramp(0.7, 0.2, 5), ramp(-0.3, 0.9, 60), ramp(0.5, -0.4, 90)))[None].expand(b, 3, h, w).contiguous()
+    R1 = torch.stack((ramp(0.1, 0.8, 15), ramp(0.6, 0.3, 6), ramp(-0.2, 0.5, 190)))[None].expand(b, 3, h, w).contiguous()
+    R2 = torch.rand(b, 3, h, w, generator=gen) * 100
+    depth = torch.rand(b, h, w, generator=gen) * 20 + 2
+    T_R2L = torch.tensor([0, 0, 0, -0.54, 0, 0.0]).expand(b, 6) + torch.randn(b, 6, generator=gen) * 0.01
+    T_21 = torch.randn(b, 6, generator=gen) * 0.03
+    K, Kinv = _kitti_K(b, h, w)
+    cpu = [x.clone().requires_grad_(True) for x in (depth, T_R2L, T_21)]
+    ref = og.dvo_photometric_loss(R2, L2, R1, cpu[0], cpu[1], cpu[2], K)
+    ref.backward()
+    gd, gp = depth.clone().to(DEV).requires_grad_(True), torch.stack((T_R2L, T_21)).to(DEV).requires_grad_(True)
+    out = PhotoLossFn.apply(R2.to(DEV), gd, gp, K.to(DEV), Kinv.to(DEV), None, L.POSE_SE3 | L.PIXEL_COORDS,
+                            L2.to(DEV), R1.to(DEV))
+    out.backward()
+    assert rel_err(out, ref) < TOL
+    assert outliers(gd.grad, cpu[0].grad, TOL) <= 4
+    assert rel_err(gp.grad[0], cpu[1].grad) < TOL and rel_err(gp.grad[1], cpu[2].grad) < TOL

@@ -192,3 +192,15 @@ def test_step_train_sfm():
             _check_digest(g, grads["pose"], "g_pose_")
     _check_params(g, "disp", dsd, 2e-4)
     _check_params(g, "pose", psd, 2e-4)
+
+
+def test_se3_expmap():
+    """Oracle SE3 exponential map (forward and the reference's hand-written backward, incl. the theta -> 0 branch)
+    against vectors produced by the reference's se3_generate.py."""
+    g = load_golden("se3_expmap")
+    vec = t(g["vec"]).double().requires_grad_(True)
+    out = geometry.se3_exp(vec)
+    ref = t(g["out"])[:, 0, :3, :]
+    assert rel_err(out, ref) < 1e-6
+    (out * t(g["wt"])[:, 0, :3, :]).sum().backward()
+    assert rel_err(vec.grad, g["g_vec"]) < 1e-5
