@@ -18,10 +18,16 @@
 //
 // Layouts are the reference's (NCHW activations, OIHW / IOHW weights): nothing is repacked between steps.
 #include "dvf_common.h"
+#include <string.h>
+#include "conv_pipe.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using dvfp::f32x16;
+using dvfp::tensor_rsrc;
+using dvfp::OOB;
+using dvfp::bload;
+using dvfp::apply_act;
 
 struct ClassDev { int py, px, by, bx, TA, TB, OHc, OWc, tap0; };
 
@@ -45,27 +51,6 @@ struct GatherArgs {
     int PSmax, Tmax, WD; // LDS carve: patch CK*PSmax | weights Tmax*CK*COTP | wdec WD | tapB Tmax | inv 64
     int tapmap[52];      // class c uses tapmap[cls[c].tap0 + t]: class tap -> tap index of the stored kernel
 };
-
-// Raw buffer descriptor over a whole tensor, built from wave-uniform values (readfirstlane keeps hipcc from
-// wrapping every load in a waterfall loop).  num_records is 2^31-16: the per-lane offset (voffset) of a valid element is
-// always below it, and an invalid element is requested at voffset 0x80000000, which the hardware range check turns
-// into a load of 0.0f -- exactly the zero padding the LDS images need.  The scalar offset (soffset) carries the
-// row base; it is added to the address but is not part of the range check.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t tensor_rsrc(const void *p) {
-    const uint64_t v = reinterpret_cast<uint64_t>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, 0x7FFFFFF0, 0x00020000);
-}
-constexpr unsigned OOB = 0x80000000u;
-__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-
-__device__ __forceinline__ float apply_act(float v, int act, float alpha, float beta) {
-    if (act == DVF_ACT_RELU) return fmaxf(v, 0.f);
-    if (act == DVF_ACT_SIGMOID_AFFINE) return alpha * (1.f / (1.f + expf(-v))) + beta;
-    return v;
-}
 
 // MT x 32 output channels, 4*NT tiles of 32 pixels per block, CK = 2*CKH reduction channels per LDS chunk.
 template <int MT, int NT, int CKH>
@@ -699,6 +684,8 @@ int scatter_classes(int S, int pad, int KH, int KW, int OH, int OW, ClassSpec *c
     return n;
 }
 
+#include "conv_pipe_host.h"
+
 int check_desc(const dvf_conv_desc *d) {
     if (!d) return DVF_ERR_INVALID_ARG;
     if (d->N <= 0 || d->C_in <= 0 || d->C_out <= 0 || d->H_in <= 0 || d->W_in <= 0 || d->H_out <= 0 || d->W_out <= 0)
@@ -716,6 +703,50 @@ int check_segs(const dvf_conv_desc *d, const int *seg_channels, int nseg) {
         tot += seg_channels[s];
     }
     return tot == d->C_in ? DVF_OK : DVF_ERR_INVALID_ARG;
+}
+
+
+// ---- op builders shared by the packed entry points
+int make_fwd_op(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg, const float *bias,
+                float *out, PipeOp &op) {
+    PipeArgs &a = op.a;
+    a = PipeArgs{};
+    for (int s = 0; s < nseg; ++s) {
+        a.in[s] = in_segs ? in_segs[s] : nullptr;
+        a.segC[s] = seg_channels[s];
+    }
+    a.nseg = nseg; a.M = d->C_out; a.bias = bias; a.out = out;
+    a.N = d->N; a.IH = d->H_in; a.IW = d->W_in; a.OH = d->H_out; a.OW = d->W_out;
+    a.act = d->act; a.alpha = d->alpha; a.beta = d->beta;
+    op.KK = d->KH * d->KW; op.m_base = 0; op.Mtot = d->C_out; op.Rtot = d->C_in;
+    if (!d->transposed) {
+        op.w_mode = 0; op.ncls = 1; op.covers = true;
+        op.cls[0] = ClassSpec{1, 0, 0, d->stride, -d->pad, -d->pad, d->KH, d->KW, d->H_out, d->W_out, {0}};
+        for (int t = 0; t < op.KK; ++t) op.cls[0].tapmap[t] = t;
+    } else {
+        op.w_mode = 1;
+        op.ncls = scatter_classes(d->stride, d->pad, d->KH, d->KW, d->H_out, d->W_out, op.cls, &op.covers);
+    }
+    return op.ncls >= 1 ? DVF_OK : DVF_ERR_UNSUPPORTED;
+}
+
+int make_dgrad_op(const dvf_conv_desc *d, const float *dpre, float *din, int off, int segc, PipeOp &op) {
+    PipeArgs &a = op.a;
+    a = PipeArgs{};
+    a.in[0] = dpre; a.segC[0] = d->C_out; a.nseg = 1;
+    a.M = segc; a.bias = nullptr; a.out = din;
+    a.N = d->N; a.IH = d->H_out; a.IW = d->W_out; a.OH = d->H_in; a.OW = d->W_in;
+    a.act = DVF_ACT_NONE;
+    op.KK = d->KH * d->KW; op.m_base = off; op.Mtot = d->C_in; op.Rtot = d->C_out;
+    if (!d->transposed) {
+        op.w_mode = 1;
+        op.ncls = scatter_classes(d->stride, d->pad, d->KH, d->KW, d->H_in, d->W_in, op.cls, &op.covers);
+    } else {
+        op.w_mode = 0; op.ncls = 1; op.covers = true;
+        op.cls[0] = ClassSpec{1, 0, 0, d->stride, -d->pad, -d->pad, d->KH, d->KW, d->H_in, d->W_in, {0}};
+        for (int t = 0; t < op.KK; ++t) op.cls[0].tapmap[t] = t;
+    }
+    return op.ncls >= 1 ? DVF_OK : DVF_ERR_UNSUPPORTED;
 }
 
 }  // namespace
@@ -873,6 +904,173 @@ int dvf_act_bwd(const float *dy, const float *y, float *dpre, float *dbias, int 
     const int64_t planes = (int64_t)N * C;
     while (chunks > 1 && planes * chunks > 16384) chunks >>= 1;
     act_bwd_kernel<<<(unsigned)(planes * chunks), 256, 0, st>>>(dy, y, dpre, dbias, C, HW, act, alpha, beta, chunks);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+
+}  // extern "C"
+
+namespace {
+// ---- packed-weight fast path (conv_pipe_kernel)
+int64_t pipe_sizes(const dvf_conv_desc *d, const int *seg_channels, int nseg, int op_kind, bool want_ws) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    rc = check_segs(d, seg_channels, nseg);
+    if (rc) return rc;
+    PipeOp op;
+    int64_t total = 0, nf = 0, wf = 0, wmax = 0;
+    if (op_kind == 0) {
+        rc = make_fwd_op(d, nullptr, seg_channels, nseg, nullptr, nullptr, op);
+        if (rc) return rc;
+        rc = pipe_pack(op, nullptr, nullptr, &nf, &wf, nullptr);
+        return rc ? rc : (want_ws ? wf : nf);
+    }
+    if (op_kind != 1) return DVF_ERR_INVALID_ARG;
+    int off = 0;
+    for (int s = 0; s < nseg; ++s) {
+        rc = make_dgrad_op(d, nullptr, nullptr, off, seg_channels[s], op);
+        if (rc) return rc;
+        rc = pipe_pack(op, nullptr, nullptr, &nf, &wf, nullptr);
+        if (rc) return rc;
+        total += nf;
+        wmax = wf > wmax ? wf : wmax;
+        off += seg_channels[s];
+    }
+    return want_ws ? wmax : total;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t dvf_conv2d_packed_floats(const dvf_conv_desc *d, const int *seg_channels, int nseg, int op_kind) {
+    return pipe_sizes(d, seg_channels, nseg, op_kind, false);
+}
+
+int64_t dvf_conv2d_ws_floats(const dvf_conv_desc *d, const int *seg_channels, int nseg, int op_kind) {
+    return pipe_sizes(d, seg_channels, nseg, op_kind, true);
+}
+
+int dvf_conv2d_pack(const dvf_conv_desc *d, const int *seg_channels, int nseg, int op_kind, const float *w, float *packed,
+                    void *stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    rc = check_segs(d, seg_channels, nseg);
+    if (rc) return rc;
+    if (!w || !packed) return DVF_ERR_INVALID_ARG;
+    PipeOp op;
+    int64_t nf = 0;
+    if (op_kind == 0) {
+        rc = make_fwd_op(d, nullptr, seg_channels, nseg, nullptr, nullptr, op);
+        if (rc) return rc;
+        return pipe_pack(op, w, packed, &nf, nullptr, dvf_stream(stream));
+    }
+    if (op_kind != 1) return DVF_ERR_INVALID_ARG;
+    int off = 0;
+    for (int s = 0; s < nseg; ++s) {
+        rc = make_dgrad_op(d, nullptr, nullptr, off, seg_channels[s], op);
+        if (rc) return rc;
+        rc = pipe_pack(op, w, packed, &nf, nullptr, dvf_stream(stream));
+        if (rc) return rc;
+        packed += nf;
+        off += seg_channels[s];
+    }
+    return DVF_OK;
+}
+
+int dvf_conv2d_fwd_packed(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                          const float *packed, const float *bias, float *out, float *ws, int64_t ws_floats, void *stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    rc = check_segs(d, seg_channels, nseg);
+    if (rc) return rc;
+    if (!in_segs || !packed || !out) return DVF_ERR_INVALID_ARG;
+    for (int s = 0; s < nseg; ++s)
+        if (!in_segs[s]) return DVF_ERR_INVALID_ARG;
+    PipeOp op;
+    rc = make_fwd_op(d, in_segs, seg_channels, nseg, bias, out, op);
+    if (rc) return rc;
+    return pipe_run(op, packed, ws, ws_floats, dvf_stream(stream));
+}
+
+int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const float *packed, float *const *din_segs,
+                            const int *seg_channels, int nseg, float *ws, int64_t ws_floats, void *stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    rc = check_segs(d, seg_channels, nseg);
+    if (rc) return rc;
+    if (!dpre || !packed || !din_segs) return DVF_ERR_INVALID_ARG;
+    PipeOp op;
+    int off = 0;
+    for (int s = 0; s < nseg; ++s) {
+        rc = make_dgrad_op(d, dpre, din_segs[s], off, seg_channels[s], op);
+        if (rc) return rc;
+        int64_t nf = 0;
+        if (din_segs[s]) {
+            rc = pipe_run(op, packed, ws, ws_floats, dvf_stream(stream));
+            if (rc) return rc;
+        }
+        rc = pipe_pack(op, nullptr, nullptr, &nf, nullptr, nullptr);
+        if (rc) return rc;
+        packed += nf;
+        off += seg_channels[s];
+    }
+    return DVF_OK;
+}
+
+
+// ---- batched packing: every convolution's job in one launch per optimizer step
+int dvf_conv2d_pack_jobs(const dvf_conv_desc *d, const int *seg_channels, int nseg, int op_kind, const float *w, float *packed,
+                         void *jobs_host, int max_jobs, int *blocks_out, int *lds_bytes_out) {
+    static_assert(sizeof(PackArgs) <= DVF_PACK_JOB_BYTES, "DVF_PACK_JOB_BYTES too small");
+    int rc = check_desc(d);
+    if (rc) return rc;
+    rc = check_segs(d, seg_channels, nseg);
+    if (rc) return rc;
+    if (!w || !packed || !jobs_host || !blocks_out || max_jobs < 1) return DVF_ERR_INVALID_ARG;
+    char *out = static_cast<char *>(jobs_host);
+    PipeOp op;
+    int64_t nf = 0;
+    int njobs = 0;
+    auto emit = [&](PipeOp &o, float *dst) -> int {
+        if (njobs >= max_jobs) return DVF_ERR_INVALID_ARG;
+        PackArgs job{};
+        int r = pipe_pack(o, w, dst, &nf, nullptr, nullptr, &job, &blocks_out[njobs]);
+        if (r) return r;
+        memset(out + (size_t)njobs * DVF_PACK_JOB_BYTES, 0, DVF_PACK_JOB_BYTES);
+        memcpy(out + (size_t)njobs * DVF_PACK_JOB_BYTES, &job, sizeof(job));
+        if (lds_bytes_out) { const int l = 32 * job.CK * job.KK * 4; if (l > *lds_bytes_out) *lds_bytes_out = l; }
+        ++njobs;
+        return DVF_OK;
+    };
+    if (op_kind == 0) {
+        rc = make_fwd_op(d, nullptr, seg_channels, nseg, nullptr, nullptr, op);
+        if (rc) return rc;
+        rc = emit(op, packed);
+        return rc ? rc : njobs;
+    }
+    if (op_kind != 1) return DVF_ERR_INVALID_ARG;
+    int off = 0;
+    for (int s = 0; s < nseg; ++s) {
+        rc = make_dgrad_op(d, nullptr, nullptr, off, seg_channels[s], op);
+        if (rc) return rc;
+        rc = emit(op, packed);
+        if (rc) return rc;
+        packed += nf;
+        off += seg_channels[s];
+    }
+    return njobs;
+}
+
+int dvf_conv2d_pack_batch(const void *jobs_dev, const int *block_prefix_dev, int njobs, int total_blocks, int lds_bytes,
+                          void *stream) {
+    if (!jobs_dev || !block_prefix_dev || njobs < 1 || total_blocks < 1 || lds_bytes < 4 || lds_bytes > 64 * 1024)
+        return DVF_ERR_INVALID_ARG;
+    static_assert(DVF_PACK_JOB_BYTES % alignof(PackArgs) == 0, "job stride");
+    static_assert(sizeof(PackArgs) == DVF_PACK_JOB_BYTES, "job stride");
+    conv_pack_batch_kernel<<<total_blocks, 256, lds_bytes, dvf_stream(stream)>>>(
+        static_cast<const PackArgs *>(jobs_dev), block_prefix_dev, njobs);
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }

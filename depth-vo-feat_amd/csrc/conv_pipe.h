@@ -1,0 +1,454 @@
+// Pipelined gather-form convolution kernel (shared by conv.hip and the conv_pipe_inst*.hip instantiation units).
+//
+// GEMM view: M = output channels (MFMA rows), N = 32-pixel tiles (one pixel per lane -> coalesced NCHW stores),
+// K = (channel pair) x taps, v_mfma_f32_32x32x2_f32 (exact fp32).  The kernel is built around LDS-DMA
+// (buffer_load ... lds): while the MFMAs consume reduction chunk g from one LDS stage, the loads of chunk g+1 land in
+// the other stage without passing through registers, and their issue is interleaved with the MFMAs of chunk g so that
+// even one wave per SIMD keeps the matrix pipe busy.  Two things make the DMA form possible:
+//
+//  * weights are PRE-PACKED (conv_pack_kernel in conv.hip) into the exact LDS image of a chunk,
+//        Wp[class][m-block][chunk][kernel row][cp-group][tap in row][m-tile][lane][VW]
+//    (lane = 32*(r&1) + (m&31), VW channel pairs per lane, rows zero-padded from TB to TBU taps), so a chunk's slab
+//    is one contiguous run fetched 1 KiB per wave-instruction and an MFMA A-fragment for VW channel pairs is ONE
+//    conflict-free ds_read_b128 / b64 at an immediate offset;
+//  * the input patch is staged as "pieces" of 64 consecutive LDS floats whose per-lane source offsets (image border ->
+//    out-of-range -> hardware zero fill, stride-2 de-interleave) are computed once per block and re-used for every
+//    channel of every chunk; only the scalar channel base changes.
+//
+// The inner loop is organised in UNITS of one kernel row (TBU taps) x VW channel pairs with no branches inside a unit.
+#pragma once
+#include "dvf_common.h"
+
+namespace dvfp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// Raw buffer descriptor over a whole tensor, built from wave-uniform values (readfirstlane keeps hipcc from
+// wrapping every load in a waterfall loop).  num_records is 2^31-16: the per-lane offset (voffset) of a valid element is
+// always below it, and an invalid element is requested at voffset 0x80000000, which the hardware range check turns
+// into a load of 0.0f -- exactly the zero padding the LDS images need.  The scalar offset (soffset) carries the
+// row base; it is added to the address but is not part of the range check.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tensor_rsrc(const void *p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, 0x7FFFFFF0, 0x00020000);
+}
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float alpha, float beta) {
+    if (act == DVF_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == DVF_ACT_SIGMOID_AFFINE) return alpha * (1.f / (1.f + expf(-v))) + beta;
+    return v;
+}
+
+struct PClass { int py, px, by, bx, TA, TB, OHc, OWc, SL, NTG; unsigned wp_off; };   // SL: slab floats; wp_off: floats
+
+struct PipeArgs {
+    const float *in[DVF_MAX_SEGS];
+    int segC[DVF_MAX_SEGS];
+    int nseg;
+    const float *wp;         // packed weights of this launch
+    const float *bias;
+    float *out;              // [N, M, OH, OW]  (or the split-K workspace [KS][N, M, OH, OW] when out_mode == 2)
+    int M, N, IH, IW, OH, OW;
+    int OS, IS, ncls;
+    PClass cls[4];
+    int act;
+    float alpha, beta;
+    int KS, NCH, out_mode, NG;            // out_mode 0: bias+act store, 1: atomicAdd, 2: plain partial store at ks*ws_slice
+    int64_t ws_slice;
+    int lsw, lsh, TGX, TGY, BW, BH, BN, tilesX, tilesY;
+    int SLmax, PSRmax;                    // LDS carve per stage: SLmax weight floats | CK * PSRmax patch floats
+    int dbg;                              // ablation switches (tools/conv_bench.py): 1 no patch loads, 2 no weight loads, 4 no MFMA
+};
+
+__host__ __device__ inline int pipe_row_stride(int RSu, int SW, int SH, int IS) {
+    // ds_read_b32 serves lanes 0-31 in one LDS cycle when they hit 32 distinct banks: rows of the SW x SH sub-tile are
+    // IS*RS floats apart, so IS*RS == SW (mod 32) is ideal.  Padding costs staging instructions (the patch is copied
+    // in 64-float pieces), so it is only applied when it is cheap; a 2-way conflict on these reads is affordable.
+    if (SH == 1 || SW >= 32 || (SW % IS) != 0) return RSu;
+    const int mod = 32 / IS, want = (SW / IS) % mod;
+    const int padded = RSu + ((want - RSu % mod) + mod) % mod;
+    return (padded * 8 <= RSu * 9) ? padded : RSu;
+}
+
+struct PipeGeo { int PH, PW, PWH, RS, PSR, NPI; };
+__host__ __device__ inline PipeGeo pipe_geo(int BH, int BW, int BN, int IS, int TA, int TB, int SW, int SH) {
+    PipeGeo g;
+    g.PH = (BH - 1) * IS + TA;
+    g.PW = (BW - 1) * IS + TB;
+    g.PWH = (g.PW + 1) >> 1;
+    g.RS = pipe_row_stride(IS == 2 ? 2 * g.PWH : g.PW, SW, SH, IS);
+    g.PSR = (BN * g.PH * g.RS + 63) & ~63;
+    g.NPI = g.PSR >> 6;
+    return g;
+}
+
+template <int V> struct fvec;
+template <> struct fvec<1> { typedef float type; };
+template <> struct fvec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct fvec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+// MT x 32 channels per wave, NT pixel tiles per wave, WM x (4/WM) MFMA waves, CK = 2*CKH channels per chunk, TBU
+// taps per unit.  The block has SIX waves: waves 0-3 only read fragments from LDS and issue MFMAs; waves 4 and 5 are
+// producers that issue the LDS-DMA loads of the even / odd chunks (they need no accumulators, so they can hold the
+// per-lane source offset of every patch piece in registers) -- their scalar-heavy bookkeeping issues from their own
+// instruction streams instead of stalling an MFMA wave's.  Three LDS stages: chunk g+2 is issued while chunk g is
+// consumed, and because each producer only ever has ONE chunk in flight, "my chunk has landed" is a plain vmcnt(0).
+constexpr int PIPE_THREADS = 384;
+constexpr int PIPE_STAGES = 3;
+constexpr int PIPE_MAXNPI = 32;    // patch pieces per channel (per-channel patch <= 2048 floats)
+
+template <int MT, int NT, int WM, int CKH, int TBU>
+__global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs a) {
+    constexpr int CK = 2 * CKH, VW = CKH >= 4 ? 4 : CKH, CPG = CKH / VW, MTW = MT * WM;
+    constexpr int UNITF = TBU * MTW * 64 * VW;             // packed floats per unit
+    typedef typename fvec<VW>::type avec;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int stage_floats = a.SLmax + CK * a.PSRmax;
+    const int tid = threadIdx.x, lane = tid & 63, nl = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int zc = blockIdx.z % a.ncls, zr = blockIdx.z / a.ncls;
+    const int ng = zr / a.KS, ks = zr - ng * a.KS;
+    const PClass c = a.cls[zc];
+    const int tX = blockIdx.x % a.tilesX, tY = blockIdx.x / a.tilesX;
+    const int oy0 = tY * a.BH, ox0 = tX * a.BW, n0 = ng * a.BN;
+    if (oy0 >= c.OHc || ox0 >= c.OWc) return;              // tile outside this (smaller) class: whole block exits
+    const int mb = blockIdx.y;
+    const int SW = 1 << a.lsw, SH = 1 << a.lsh;
+    const PipeGeo geo = pipe_geo(a.BH, a.BW, a.BN, a.IS, c.TA, TBU, SW, SH);   // TBU >= TB columns staged
+    const int RS = geo.RS, PSR = geo.PSR, PWH = geo.PWH;
+    const int g_begin = (int)(((int64_t)a.NCH * ks) / a.KS), g_end = (int)(((int64_t)a.NCH * (ks + 1)) / a.KS);
+
+    if (wave >= 4) {
+        // ================================================================== producer waves: all LDS-DMA loads
+        const int par = wave - 4;                          // this producer owns chunks g with (g - g_begin) % 2 == par
+        const int NWP = c.SL >> 8;                         // 1 KiB weight pieces per chunk
+        const int iy0 = oy0 * a.IS + c.by, ix0 = ox0 * a.IS + c.bx;
+        unsigned pvoff[PIPE_MAXNPI];                       // per-lane source offset of every patch piece
+        int pbn[PIPE_MAXNPI];
+        {
+            const int per_img = geo.PH * RS;
+            const float inv_img = 1.0f / (float)per_img, inv_rs = 1.0f / (float)RS;
+#pragma unroll
+            for (int kk = 0; kk < PIPE_MAXNPI; ++kk) {
+                pvoff[kk] = OOB;
+                pbn[kk] = 0;
+                if (kk < geo.NPI) {
+                    const int p = (kk << 6) + lane;
+                    // exact small-integer division through fp32 (p < 2^16): estimate, then one correction step
+                    int bn = (int)((float)p * inv_img);
+                    bn += (p - bn * per_img >= per_img) - (p - bn * per_img < 0);
+                    const int rem = p - bn * per_img;
+                    int row = (int)((float)rem * inv_rs);
+                    row += (rem - row * RS >= RS) - (rem - row * RS < 0);
+                    const int col = rem - row * RS;
+                    int cs = col;
+                    bool ok = (bn < a.BN) && (n0 + bn < a.N);
+                    if (a.IS == 2) {
+                        cs = col < PWH ? 2 * col : 2 * (col - PWH) + 1;
+                        ok = ok && (col < 2 * PWH);
+                    }
+                    ok = ok && (cs < geo.PW);
+                    const int iy = iy0 + row, ix = ix0 + cs;
+                    ok = ok && (iy >= 0) && (iy < a.IH) && (ix >= 0) && (ix < a.IW);
+                    pvoff[kk] = ok ? (unsigned)((iy * a.IW + ix) << 2) : OOB;
+                    pbn[kk] = ok ? bn : 0;
+                }
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rs_w = tensor_rsrc(a.wp);
+        unsigned voob = OOB;
+        asm volatile("" : "+v"(voob));                     // keep the constant in a VGPR (no per-use v_mov)
+        int iseg = 0, iseg_first = 0;
+        auto issue = [&](int g, int st) {
+            while (true) {
+                const int nchs = (a.segC[iseg] + CK - 1) / CK;
+                if (g < iseg_first + nchs) break;
+                iseg_first += nchs;
+                ++iseg;
+            }
+            float *wl = smem + st * stage_floats;
+            float *patch = wl + a.SLmax;
+            if (!(a.dbg & 2)) {
+                const unsigned slab = (c.wp_off + (unsigned)(mb * a.NCH + g) * (unsigned)c.SL) << 2;
+                for (int p = 0; p < NWP; ++p)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)(wl + (p << 8)), 16, (unsigned)lane << 4,
+                                                             slab + ((unsigned)p << 10), 0, 0);
+            }
+            if (!(a.dbg & 1)) {
+                const int segc = a.segC[iseg];
+                const int c0 = (g - iseg_first) * CK;
+                const int nch = min(CK, segc - c0);
+                const __amdgpu_buffer_rsrc_t rs_in = tensor_rsrc(a.in[iseg]);
+                const unsigned plane = (unsigned)(a.IH * a.IW) << 2;
+                const unsigned img = (unsigned)segc * plane;
+                const unsigned cb = (unsigned)(n0 * segc + c0) * plane;
+                // (no vector ALU work per piece: a VALU instruction costs the MFMA wave sharing this SIMD 6-8 cycles)
+                for (int ci = 0; ci < CK; ++ci) {
+                    float *dst = patch + ci * PSR;
+                    if (ci >= nch) {                       // channel tail of the segment: zero-fill
+#pragma unroll
+                        for (int kk = 0; kk < PIPE_MAXNPI; ++kk)
+                            if (kk < geo.NPI)
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(dst + (kk << 6)), 4, voob, 0u, 0, 0);
+                    } else if (a.BN > 1) {
+                        const unsigned soff = cb + (unsigned)ci * plane;
+#pragma unroll
+                        for (int kk = 0; kk < PIPE_MAXNPI; ++kk)
+                            if (kk < geo.NPI) {
+                                const unsigned vo = (pvoff[kk] == OOB) ? OOB : pvoff[kk] + (unsigned)pbn[kk] * img;
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(dst + (kk << 6)), 4, vo, soff, 0, 0);
+                            }
+                    } else {
+                        const unsigned soff = cb + (unsigned)ci * plane;
+#pragma unroll
+                        for (int kk = 0; kk < PIPE_MAXNPI; ++kk)
+                            if (kk < geo.NPI)
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(dst + (kk << 6)), 4, pvoff[kk], soff, 0, 0);
+                    }
+                }
+            }
+        };
+        if (a.dbg & 8) return;
+        if (g_begin + par < g_end) issue(g_begin + par, par);
+        int st = par + 2;                                  // stage of this producer's next chunk (mod PIPE_STAGES)
+        for (int g = g_begin; g < g_end; ++g) {
+            if (((g - g_begin) & 1) == par) {
+                // my chunk g must have landed before anyone passes this barrier; chunk g-1 is fully consumed after it,
+                // which frees the stage chunk g+2 goes to
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (st >= PIPE_STAGES) st -= PIPE_STAGES;
+                if (g + 2 < g_end) issue(g + 2, st);
+                st += 2;
+            } else {
+                __builtin_amdgcn_s_barrier();              // the other producer's chunk: just take part in the barrier
+            }
+        }
+        return;
+    }
+
+    // ====================================================================== MFMA waves
+    const int wm = wave % WM, wn = wave / WM;
+    // bias of the block's channels -> LDS (visible after the first chunk barrier): the epilogue must not chain 32
+    // dependent global loads
+    float *bias_lds = smem + PIPE_STAGES * stage_floats;
+    if (tid < 32 * MTW) {
+        const int mm = mb * (32 * MTW) + tid;
+        bias_lds[tid] = (a.bias && a.out_mode == 0 && mm < a.M) ? a.bias[mm] : 0.f;
+    }
+    const int NU = c.NTG * CPG;                            // units per chunk
+    int opy[NT], opx[NT], opn[NT];
+    int bj[NT][VW];                                        // B-fragment base (floats) per tile and channel pair
+    const int pxl = nl & (SW - 1), pyl = (nl >> a.lsw) & (SH - 1), pnl = nl >> (a.lsw + a.lsh);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int q = wn * NT + i, tx = q % a.TGX, tyn = q / a.TGX, ty = tyn % a.TGY, tn = tyn / a.TGY;
+        const int SN = 32 >> (a.lsw + a.lsh);
+        opy[i] = ty * SH + pyl;
+        opx[i] = tx * SW + pxl;
+        opn[i] = tn * SN + pnl;
+        const int bbase = kh * PSR + (opn[i] * geo.PH + opy[i] * a.IS) * RS + opx[i];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) bj[i][j] = bbase + j * 2 * PSR;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
+
+    // The chunk in stage `st`, unit by unit.  A unit is one kernel ROW (ta) x VW channel pairs: its TBU taps are
+    // consecutive floats of a patch row, so their B fragments share ONE row address per (tile, channel pair) and differ
+    // by immediate offsets -- a plain VALU instruction between two MFMAs costs 6-8 cycles of matrix-pipe time on gfx950
+    // (tools/micro/mfma_mix.hip), scalar and LDS instructions cost none, so address arithmetic is kept scalar except
+    // for that one add per row.  The next unit's fragments are fetched behind the current unit's MFMAs
+    // (unconditionally: past the end of the chunk they read LDS that nobody uses).
+    auto consume = [&](int st, auto isc) {
+        constexpr int IS = decltype(isc)::value;
+        const float *wl = smem + st * stage_floats;
+        const float *patch = wl + a.SLmax;
+        const float *ap = wl + (wm * MT) * 64 * VW + lane * VW;
+        avec af[2][TBU][MT];
+        float bf[2][TBU][NT][VW];
+        int lta = 0, lcpg = 0, lk = 0;                     // load iterator (scalar): next unit to fetch
+        auto load_b = [&](auto bufc) {
+            constexpr int buf = decltype(bufc)::value;
+            const float *prow0 = patch + (lta * RS + lcpg * (2 * VW) * PSR);
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < VW; ++j) {
+                    const float *prow = prow0 + bj[i][j];
+                    if constexpr (IS == 1) {
+#pragma unroll
+                        for (int u = 0; u < TBU; ++u) bf[buf][u][i][j] = prow[u];
+                    } else {
+                        const float *prow2 = prow + PWH;   // odd columns of the de-interleaved row
+#pragma unroll
+                        for (int u = 0; u < TBU; ++u) bf[buf][u][i][j] = (u & 1) ? prow2[u >> 1] : prow[u >> 1];
+                    }
+                }
+        };
+        auto load_a = [&](auto bufc, auto uc) {
+            constexpr int buf = decltype(bufc)::value, u = decltype(uc)::value;
+            const float *aptr = ap + lk * UNITF;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[buf][u][m] = *reinterpret_cast<const avec *>(aptr + (u * MTW + m) * 64 * VW);
+        };
+        auto advance = [&]() {
+            ++lk;
+            const bool wrap = (lcpg + 1 == CPG);
+            lcpg = wrap ? 0 : lcpg + 1;
+            lta += wrap ? 1 : 0;
+        };
+        auto mma_tap = [&](auto bufc, auto uc) {
+            constexpr int buf = decltype(bufc)::value, u = decltype(uc)::value;
+#pragma unroll
+            for (int j = 0; j < VW; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float av;
+                    if constexpr (VW == 1) av = af[buf][u][m]; else av = af[buf][u][m][j];
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[buf][u][i][j], acc[m][i], 0, 0, 0);
+                }
+        };
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        // tap by tap: this unit's MFMAs of tap u, then the next unit's loads (all B rows behind tap 0, A of tap u behind
+        // tap u).  The scheduling barriers keep hipcc from sinking the loads next to their uses.
+        auto step = [&](auto bufc, auto nbufc, auto uc) {
+            mma_tap(bufc, uc);
+            if constexpr (decltype(uc)::value == 0) load_b(nbufc);
+            load_a(nbufc, uc);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto unit = [&](auto bufc, auto nbufc) {
+            step(bufc, nbufc, std::integral_constant<int, 0>{});
+            if constexpr (TBU > 1) step(bufc, nbufc, std::integral_constant<int, 1>{});
+            if constexpr (TBU > 2) step(bufc, nbufc, std::integral_constant<int, 2>{});
+            if constexpr (TBU > 3) step(bufc, nbufc, std::integral_constant<int, 3>{});
+            if constexpr (TBU > 4) step(bufc, nbufc, std::integral_constant<int, 4>{});
+            if constexpr (TBU > 5) step(bufc, nbufc, std::integral_constant<int, 5>{});
+            if constexpr (TBU > 6) step(bufc, nbufc, std::integral_constant<int, 6>{});
+            advance();
+        };
+        load_b(B0{});
+        load_a(B0{}, std::integral_constant<int, 0>{});
+        if constexpr (TBU > 1) load_a(B0{}, std::integral_constant<int, 1>{});
+        if constexpr (TBU > 2) load_a(B0{}, std::integral_constant<int, 2>{});
+        if constexpr (TBU > 3) load_a(B0{}, std::integral_constant<int, 3>{});
+        if constexpr (TBU > 4) load_a(B0{}, std::integral_constant<int, 4>{});
+        if constexpr (TBU > 5) load_a(B0{}, std::integral_constant<int, 5>{});
+        if constexpr (TBU > 6) load_a(B0{}, std::integral_constant<int, 6>{});
+        advance();
+        __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < NU; k += 2) {
+            unit(B0{}, B1{});
+            if (k + 1 < NU) unit(B1{}, B0{});
+        }
+    };
+
+    if (!(a.dbg & 8)) {
+        int st = 0;
+        for (int g = g_begin; g < g_end; ++g) {
+            __syncthreads();          // chunk g has landed (its producer waited for it) and chunk g-1 is fully consumed
+            if (!(a.dbg & 4)) {
+                if (a.IS == 2) consume(st, std::integral_constant<int, 2>{});
+                else consume(st, std::integral_constant<int, 1>{});
+            }
+            st = (st + 1 == PIPE_STAGES) ? 0 : st + 1;
+        }
+    }
+
+    // ---- epilogue: D[row = channel][col = pixel]; lanes 0-31 / 32-63 hold channel rows +0 / +4
+    if (a.dbg & 16) return;
+    const int m0 = mb * (32 * MTW) + wm * (32 * MT);
+    float *outp = a.out + (a.out_mode == 2 ? (int64_t)ks * a.ws_slice : 0);
+    const int64_t HW = (int64_t)a.OH * a.OW;
+    float bv[MT][16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[m][r] = bias_lds[wm * (32 * MT) + 4 * kh + m * 32 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int oy = oy0 + opy[i], ox = ox0 + opx[i], n = n0 + opn[i];
+        const int Y = oy * a.OS + c.py, X = ox * a.OS + c.px;
+        const bool pok = (oy < c.OHc) && (ox < c.OWc) && (Y < a.OH) && (X < a.OW) && (opn[i] < a.BN) && (n < a.N);
+        float *pbase = outp + ((int64_t)n * a.M + m0 + 4 * kh) * HW + (int64_t)Y * a.OW + X;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = m * 32 + (r & 3) + 8 * (r >> 2);
+                const int mm = m0 + 4 * kh + ml;
+                if (pok && mm < a.M) {
+                    float *op = pbase + (int64_t)ml * HW;
+                    float v = acc[m][i][r];
+                    if (a.out_mode == 0) {
+                        *op = apply_act(v + bv[m][r], a.act, a.alpha, a.beta);
+                    } else if (a.out_mode == 1) {
+                        atomicAdd(op, v);
+                    } else {
+                        *op = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Launch one (MT, NT, WM) family; CKH in {2,4,8} and TBU in {2,3,4} are dispatched inside.  Defined in the
+// conv_pipe_inst*.hip units (explicit specialisations), declared here for conv.hip.
+template <int MT, int NT, int WM>
+int launch_pipe_family(const PipeArgs &a, int CKH, int TBU, dim3 grid, size_t lds, hipStream_t st);
+
+// blocks that use more than 64 KiB of LDS need the opt-in attribute (set once per kernel)
+template <int MT, int NT, int WM, int CKH, int TBU>
+inline int launch_pipe_one(const PipeArgs &a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool big_lds = false;
+    if (lds > 64 * 1024 && !big_lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pipe_kernel<MT, NT, WM, CKH, TBU>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return DVF_ERR_LAUNCH;
+        big_lds = true;
+    }
+    conv_pipe_kernel<MT, NT, WM, CKH, TBU><<<grid, PIPE_THREADS, lds, st>>>(a);
+    return hipGetLastError() == hipSuccess ? DVF_OK : DVF_ERR_LAUNCH;
+}
+
+template <int MT, int NT, int WM, int CKH>
+inline int launch_pipe_tbu(const PipeArgs &a, int TBU, dim3 grid, size_t lds, hipStream_t st) {
+    switch (TBU) {
+        case 1: return launch_pipe_one<MT, NT, WM, CKH, 1>(a, grid, lds, st);
+        case 2: return launch_pipe_one<MT, NT, WM, CKH, 2>(a, grid, lds, st);
+        case 3: return launch_pipe_one<MT, NT, WM, CKH, 3>(a, grid, lds, st);
+        case 4: return launch_pipe_one<MT, NT, WM, CKH, 4>(a, grid, lds, st);
+        case 5: if constexpr (CKH <= 4 && WM == 1) return launch_pipe_one<MT, NT, WM, CKH, 5>(a, grid, lds, st); else return DVF_ERR_UNSUPPORTED;
+        case 7: if constexpr (CKH <= 4 && WM == 1) return launch_pipe_one<MT, NT, WM, CKH, 7>(a, grid, lds, st); else return DVF_ERR_UNSUPPORTED;
+        default: return DVF_ERR_UNSUPPORTED;
+    }
+}
+
+#define DVF_PIPE_FAMILY(MT, NT, WM)                                                                              \
+    template <>                                                                                                  \
+    int launch_pipe_family<MT, NT, WM>(const PipeArgs &a, int CKH, int TBU, dim3 grid, size_t lds, hipStream_t st) { \
+        switch (CKH) {                                                                                           \
+            case 2: return launch_pipe_tbu<MT, NT, WM, 2>(a, TBU, grid, lds, st);                                \
+            case 4: return launch_pipe_tbu<MT, NT, WM, 4>(a, TBU, grid, lds, st);                                \
+            case 8: return launch_pipe_tbu<MT, NT, WM, 8>(a, TBU, grid, lds, st);                                \
+            default: return DVF_ERR_UNSUPPORTED;                                                                 \
+        }                                                                                                        \
+    }
+
+}  // namespace dvfp

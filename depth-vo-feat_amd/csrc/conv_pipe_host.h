@@ -1,0 +1,351 @@
+// Host side of the pipelined convolution (included by conv.hip inside its anonymous namespace): weight packing,
+// split-K reduction, planning and launch.
+using dvfp::PClass;
+using dvfp::PipeArgs;
+using dvfp::PipeGeo;
+using dvfp::pipe_geo;
+using dvfp::PIPE_MAXNPI;
+
+// ------------------------------------------------------------------------------------------------ weight packing
+struct alignas(8) PackArgsBody {
+    const float *w;
+    float *wp;
+    int w_mode;              // 0: w[((m_base+m)*Rtot + r)*KK + tap]   1: w[(r*Mtot + m_base+m)*KK + tap]
+    int Mtot, Rtot, KK, m_base, M;
+    int nseg, segC[DVF_MAX_SEGS];
+    int ncls, NCH, CK, MB, VW, TBU;
+    int TB[4], TA[4];        // taps per kernel row / kernel rows of each class
+    int SL[4];
+    unsigned wp_off[4];
+    signed char tapmap[4][52];   // class tap -> stored tap
+};
+// jobs of the batched launch are stored with a fixed DVF_PACK_JOB_BYTES stride
+struct PackArgs : PackArgsBody { char pad[DVF_PACK_JOB_BYTES - sizeof(PackArgsBody)]; };
+
+// One block per (chunk, 32-channel m-tile): the source weights of the tile (32 x CK x KK floats) are staged in LDS with
+// coalesced reads, then every packed element of the tile -- for every class, including the zero padding of channel
+// tails, short kernel rows and m >= M -- is written in destination order (coalesced 4-byte lanes over contiguous runs).
+__device__ __forceinline__ void pack_block(const PackArgs &a, int g, int mt, float *S) {
+    const int tid = threadIdx.x;
+    const int MTW = a.MB >> 5, mb = mt / MTW, mtw = mt - mb * MTW, m0 = mt * 32;
+    int seg_start = 0, gg = g, segc = a.segC[0];
+    for (int s = 0; s < a.nseg; ++s) {
+        const int nchs = (a.segC[s] + a.CK - 1) / a.CK;
+        segc = a.segC[s];
+        if (gg < nchs) break;
+        gg -= nchs;
+        seg_start += a.segC[s];
+    }
+    const int c0 = gg * a.CK, nch = min(a.CK, segc - c0), r0 = seg_start + c0;
+    const int mvalid = min(32, a.M - m0);
+    const int CKK = a.CK * a.KK;
+    const int wave = tid >> 6, lane64 = tid & 63;
+    if (a.w_mode == 0) {
+        const int run = nch * a.KK;                        // contiguous floats per output channel
+        for (int m = wave; m < mvalid; m += 4) {
+            const float *src = a.w + ((int64_t)(a.m_base + m0 + m) * a.Rtot + r0) * a.KK;
+            for (int x = lane64; x < run; x += 64) S[m * CKK + x] = src[x];
+        }
+    } else {
+        const int run = mvalid * a.KK;                     // contiguous floats per reduction channel
+        const float invKK = 1.0f / (float)a.KK;
+        for (int rl = wave; rl < nch; rl += 4) {
+            const float *src = a.w + ((int64_t)(r0 + rl) * a.Mtot + a.m_base + m0) * a.KK;
+            for (int x = lane64; x < run; x += 64) {
+                const int m = (int)(((float)x + 0.5f) * invKK), tap = x - m * a.KK;    // exact for x < 2^12
+                S[m * CKK + rl * a.KK + tap] = src[x];
+            }
+        }
+    }
+    __syncthreads();
+    // destination order without divisions: a thread keeps its (lane, channel pair) and walks (unit, tap) incrementally
+    const int CKH = a.CK >> 1, CPG = CKH / a.VW, LV = 64 * a.VW;       // LV in {128, 256}
+    const int x = tid & (LV - 1), kstep = 256 / LV;
+    const int lane = x / a.VW, j = x - lane * a.VW, kh = lane >> 5, m = lane & 31;
+    for (int c = 0; c < a.ncls; ++c) {
+        const int TB = a.TB[c], NKU = a.TA[c] * CPG * a.TBU;
+        float *dst = a.wp + a.wp_off[c] + (int64_t)(mb * a.NCH + g) * a.SL[c] + (int64_t)mtw * LV + x;
+        int ku = tid / LV, u = ku, cpg = 0, ta = 0;       // ku = (ta*CPG + cpg)*TBU + u ; first ku < kstep <= 2 <= TBU... 
+        while (u >= a.TBU) { u -= a.TBU; if (++cpg == CPG) { cpg = 0; ++ta; } }
+        for (; ku < NKU; ku += kstep) {
+            const int rl = 2 * (cpg * a.VW + j) + kh;
+            float v = 0.f;
+            if (u < TB && rl < nch && m < mvalid) v = S[m * CKK + rl * a.KK + a.tapmap[c][ta * TB + u]];
+            dst[(int64_t)ku * MTW * LV] = v;
+            u += kstep;
+            while (u >= a.TBU) { u -= a.TBU; if (++cpg == CPG) { cpg = 0; ++ta; } }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_pack_kernel(const PackArgs a) {
+    extern __shared__ float S[];                           // [32][CK][KK]
+    pack_block(a, blockIdx.x, blockIdx.y, S);
+}
+
+// All packing jobs of a training step in ONE launch: block b belongs to the job j with prefix[j] <= b < prefix[j+1].
+__global__ __launch_bounds__(256) void conv_pack_batch_kernel(const PackArgs *jobs, const int *prefix, int njobs) {
+    extern __shared__ float S[];
+    int lo = 0, hi = njobs;                                // invariant: prefix[lo] <= b < prefix[hi]
+    const int b = blockIdx.x;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= b) lo = mid; else hi = mid;
+    }
+    const PackArgs &a = jobs[lo];
+    const int local = b - prefix[lo];
+    pack_block(a, local % a.NCH, local / a.NCH, S);
+}
+
+// out = act(sum_k ws[k] + bias): finishes a split-K convolution whose blocks stored plain partial tiles.
+__global__ void splitk_reduce_kernel(const float *ws, float *out, const float *bias, int KS, int64_t slice, int C, int64_t HW,
+                                     int act, float alpha, float beta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slice; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = ws[i];
+        for (int k = 1; k < KS; ++k) v += ws[i + k * slice];
+        if (bias) v += bias[(int)((i / HW) % C)];
+        out[i] = dvfp::apply_act(v, act, alpha, beta);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- host planning
+struct PipePlan {
+    int MT, NT, WM, CKH, TBU;
+    size_t lds;
+    dim3 grid;
+    int64_t packed_floats, ws_floats;
+};
+
+struct PipeOverride { int on, MT, NT, WM, CK, KS, BN, TBU; };
+inline PipeOverride pipe_override() {
+    PipeOverride o{0, 0, 0, 0, 0, 0, 0, 0};
+    if (const char *e = getenv("DVF_PIPE_PLAN"))         // "MT,NT,WM,CK,KS,BN,TBU" (0 = automatic) -- tuning tool only
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &o.MT, &o.NT, &o.WM, &o.CK, &o.KS, &o.BN, &o.TBU) >= 1) o.on = 1;
+    return o;
+}
+
+// tile arrangement for `ntile` 32-pixel tiles per block over BN images
+struct PipeTiles { int lsw, lsh, TGX, TGY, TGN, BN; double cov; };
+inline PipeTiles pipe_tiles(int OHc, int OWc, int N, int ntile, int BNwant, int IS, int TBmax) {
+    PipeTiles best{5, 0, 1, ntile, 1, 1, 1e30};
+    for (int lsn = 0; lsn <= 5; ++lsn) {
+        const int SN = 1 << lsn;
+        for (int lsw = 5 - lsn; lsw >= 0; --lsw) {
+            const int lsh = 5 - lsn - lsw, SW = 1 << lsw, SH = 1 << lsh;
+            for (int TGN = 1; TGN <= ntile; TGN *= 2) {
+                const int BN = SN * TGN;
+                if (BN != BNwant) continue;
+                for (int TGX = 1; TGX * TGN <= ntile; TGX *= 2) {
+                    const int TGY = ntile / (TGX * TGN), BW = TGX * SW, BH = TGY * SH;
+                    if ((BW - 1) * IS + TBmax > 160) continue;
+                    const double cov = (double)cdiv(OWc, BW) * BW * cdiv(OHc, BH) * BH * cdiv(N, BN) * BN;
+                    // narrow sub-tiles store / gather in short segments: prefer >= 16 pixels per row
+                    // and >= 32 per block row (full 128-byte lines per store)
+                    const double narrow = (SW >= 16 ? 0.0 : (SW == 8 ? 0.12 : 0.3)) + (BW >= 32 ? 0.0 : 0.08);
+                    const double cost = cov * (1.0 + narrow + 0.02 * lsh + 0.02 * lsn) + 1e-3 * (BW + BH);
+                    if (cost < best.cov) best = PipeTiles{lsw, lsh, TGX, TGY, TGN, BN, cost};
+                }
+            }
+        }
+    }
+    return best;
+}
+
+
+// Plan one op (all its classes share the launch).  Fills `a`'s tiling/packing fields; the same plan drives packing.
+int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
+    if (ncls < 1 || ncls > 4) return DVF_ERR_INVALID_ARG;
+    a.ncls = ncls; a.OS = cls[0].OS; a.IS = cls[0].IS;
+    int Tmax = 0, TAmax = 0, TBmax = 0, OHc = 0, OWc = 0;
+    for (int i = 0; i < ncls; ++i) {
+        const ClassSpec &c = cls[i];
+        const int T = c.TA * c.TB;
+        if (T < 1 || c.OHc <= 0 || c.OWc <= 0) return DVF_ERR_INVALID_ARG;
+        Tmax = T > Tmax ? T : Tmax; TAmax = c.TA > TAmax ? c.TA : TAmax; TBmax = c.TB > TBmax ? c.TB : TBmax;
+        OHc = c.OHc > OHc ? c.OHc : OHc; OWc = c.OWc > OWc ? c.OWc : OWc;
+    }
+    const PipeOverride ov = pipe_override();
+    int maxc = 0;
+    for (int s = 0; s < a.nseg; ++s) maxc = a.segC[s] > maxc ? a.segC[s] : maxc;
+    const int64_t px = (int64_t)OHc * OWc;                   // pixels per image per class
+    // --- taps per unit = the widest kernel row of the classes (narrower rows are zero-padded in the packed weights)
+    int TBU = TBmax;
+    if (TBU == 6) TBU = 7;
+    if (TBU > 7) return DVF_ERR_UNSUPPORTED;
+    (void)Tmax;
+    // --- block shape: channels per block (32*MT*WM) and pixel tiles per block (WN*NT)
+    int MT = a.M > 32 ? 2 : 1;
+    int BN = 1;
+    if (px <= 64) { while (BN < a.N && BN * px < 128 && BN < 32) BN *= 2; }
+    int WM = 1;
+    if (px * BN <= 64 && a.M >= 128) WM = 2;                 // two 32-pixel tiles per block at most: split waves over M
+    int NT = 2;
+    if (ov.on) {
+        if (ov.MT) MT = ov.MT;
+        if (ov.WM) WM = ov.WM;
+        if (ov.BN) BN = ov.BN;
+    }
+    if (WM == 2 || MT == 2) NT = 1;                        // (64 channels x 2 tiles per wave does not fit the register file)
+    const int WN = 4 / WM;
+    auto nblocks = [&](const PipeTiles &tp) {
+        return (int64_t)cdiv(OWc, tp.TGX << tp.lsw) * cdiv(OHc, tp.TGY << tp.lsh) * cdiv(a.M, 32 * MT * WM) *
+               cdiv(a.N, tp.BN) * ncls;
+    };
+    PipeTiles tp = pipe_tiles(OHc, OWc, a.N, WN * NT, BN, a.IS, TBmax);
+    if (tp.cov >= 1e30) return DVF_ERR_UNSUPPORTED;
+    int64_t nblk = nblocks(tp);
+    if (NT == 2 && nblk < 512 && !(ov.on && ov.NT)) {
+        PipeTiles tp1 = pipe_tiles(OHc, OWc, a.N, WN * 1, BN, a.IS, TBmax);
+        if (tp1.cov < 1e30) { NT = 1; tp = tp1; nblk = nblocks(tp); }
+    }
+    if (ov.on && ov.NT && WM == 1 && MT == 1) {
+        NT = ov.NT;
+        tp = pipe_tiles(OHc, OWc, a.N, WN * NT, BN, a.IS, TBmax);
+        if (tp.cov >= 1e30) return DVF_ERR_UNSUPPORTED;
+        nblk = nblocks(tp);
+    }
+    a.lsw = tp.lsw; a.lsh = tp.lsh; a.TGX = tp.TGX; a.TGY = tp.TGY; a.BN = tp.BN;
+    a.BW = tp.TGX << tp.lsw; a.BH = tp.TGY << tp.lsh;
+    a.tilesX = cdiv(OWc, a.BW); a.tilesY = cdiv(OHc, a.BH); a.NG = cdiv(a.N, a.BN);
+    const int SW = 1 << a.lsw, SH = 1 << a.lsh, MB = 32 * MT * WM;
+    int PSRmax = 0;
+    for (int i = 0; i < ncls; ++i) {
+        const PipeGeo g = pipe_geo(a.BH, a.BW, a.BN, a.IS, cls[i].TA, TBU, SW, SH);
+        if (g.NPI > PIPE_MAXNPI) return DVF_ERR_UNSUPPORTED;
+        PSRmax = g.PSR > PSRmax ? g.PSR : PSRmax;
+    }
+    a.PSRmax = PSRmax;
+    // --- chunk depth: largest CK in {16,8,4} whose two stages fit the LDS budget
+    auto slab = [&](int CK, int TA) { return (TA * TBU * CK * MB + 255) & ~255; };
+    auto lds_bytes = [&](int CK) { return ((size_t)dvfp::PIPE_STAGES * (slab(CK, TAmax) + (size_t)CK * PSRmax) + MB) * 4; };
+    // LDS budget: a grid of at most one block per CU may take (nearly) the whole 160 KiB; otherwise leave room for two
+    const int KS0 = nblk < 160 ? (int)(256 / nblk) : 1;     // split-K factor before clamping to the chunk count
+    const size_t PIPE_LDS_BUDGET = (nblk * KS0 <= 256 ? 150 : 76) * 1024;
+    int CK = TBU >= 5 ? 8 : 16;                          // (the 5- and 7-tap kernels are only built for CK <= 8)
+    while (CK > 4 && lds_bytes(CK) > PIPE_LDS_BUDGET) CK >>= 1;
+    while (CK > 4 && CK / 2 >= maxc) CK >>= 1;
+    if (ov.on && ov.CK) CK = ov.CK;
+    if (CK != 4 && CK != 8 && CK != 16) return DVF_ERR_UNSUPPORTED;
+    if (lds_bytes(CK) > PIPE_LDS_BUDGET) return DVF_ERR_UNSUPPORTED;
+    a.SLmax = slab(CK, TAmax);
+    a.NCH = 0;
+    for (int s = 0; s < a.nseg; ++s) a.NCH += cdiv(a.segC[s], CK);
+    const int mblocks = cdiv(a.M, MB);
+    unsigned off = 0;
+    for (int i = 0; i < ncls; ++i) {
+        const ClassSpec &c = cls[i];
+        const int SL = slab(CK, c.TA);
+        a.cls[i] = PClass{c.py, c.px, c.by, c.bx, c.TA, c.TB, c.OHc, c.OWc, SL, c.TA, off};
+        const int64_t nf = (int64_t)mblocks * a.NCH * SL;
+        if ((int64_t)off + nf >= ((int64_t)1 << 29)) return DVF_ERR_UNSUPPORTED;      // 32-bit byte offsets
+        off += (unsigned)nf;
+    }
+    pl.packed_floats = off;
+    // --- split-K: only when the grid leaves most CUs idle (one block per CU already pipelines loads under MFMAs)
+    int KS = KS0;
+    if (ov.on && ov.KS) KS = ov.KS;
+    if (KS > a.NCH) KS = a.NCH;
+    if (KS < 1) KS = 1;
+    if ((int64_t)a.NG * KS * ncls > 65535) return DVF_ERR_UNSUPPORTED;
+    a.KS = KS;
+    pl.ws_floats = KS > 1 ? (int64_t)KS * a.N * a.M * a.OH * a.OW : 0;
+    for (int s2 = 0; s2 < a.nseg; ++s2)
+        if ((int64_t)a.N * a.segC[s2] * a.IH * a.IW * 4 >= ((int64_t)1 << 31) - 16) return DVF_ERR_UNSUPPORTED;
+    pl.MT = MT; pl.NT = NT; pl.WM = WM; pl.CKH = CK / 2; pl.TBU = TBU; pl.lds = lds_bytes(CK);
+    pl.grid = dim3(a.tilesX * a.tilesY, mblocks, a.NG * KS * ncls);
+    return DVF_OK;
+}
+
+int launch_pipe(const PipeArgs &a, const PipePlan &pl, hipStream_t st) {
+    using dvfp::launch_pipe_family;
+    if (pl.WM == 2) {
+        if (pl.NT != 1) return DVF_ERR_UNSUPPORTED;
+        return pl.MT == 2 ? launch_pipe_family<2, 1, 2>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st)
+                          : launch_pipe_family<1, 1, 2>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st);
+    }
+    if (pl.WM != 1) return DVF_ERR_UNSUPPORTED;
+    if (pl.MT == 2 && pl.NT == 2) return DVF_ERR_UNSUPPORTED;
+    if (pl.MT == 2) return launch_pipe_family<2, 1, 1>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st);
+    if (pl.NT == 2) return launch_pipe_family<1, 2, 1>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st);
+    return launch_pipe_family<1, 1, 1>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st);
+}
+
+// One op instance = one (M range, reduction segments, classes) triple: Conv2d fwd, one segment of a dgrad, ...
+struct PipeOp {
+    PipeArgs a;
+    ClassSpec cls[4];
+    int ncls;
+    bool covers;
+    int w_mode, Mtot, Rtot, KK, m_base;
+};
+
+// ws: optional split-K workspace (ws_floats floats).  With it the K-splits store plain partial tiles and one pass
+// reduces them (+bias, activation); without it they accumulate with float atomics into a zeroed output.
+int pipe_run(PipeOp &op, const float *packed, float *ws, int64_t ws_floats, hipStream_t st) {
+    PipePlan pl;
+    int rc = plan_pipe(op.a, op.cls, op.ncls, pl);
+    if (rc) return rc;
+    PipeArgs &a = op.a;
+    a.wp = packed;
+    const int64_t HW = (int64_t)a.OH * a.OW, total = (int64_t)a.N * a.M * HW;
+    float *out = a.out;
+    int mode = 0;
+    if (!op.covers) mode = 1;
+    else if (a.KS > 1) mode = (ws && ws_floats >= pl.ws_floats) ? 2 : 1;
+    if (mode == 1 && hipMemsetAsync(out, 0, sizeof(float) * total, st) != hipSuccess) return DVF_ERR_LAUNCH;
+    a.out_mode = mode;
+    if (mode == 2) { a.out = ws; a.ws_slice = total; }
+    if (const char *e = getenv("DVF_DBG")) a.dbg = atoi(e);
+    if (getenv("DVF_PIPE_DEBUG"))
+        fprintf(stderr, "[pipe] M %d chunks %d N %d out %dx%d cls %d | MT %d NT %d WM %d CK %d TBU %d KS %d BN %d tile %dx%d "
+                "(sub %dx%d) grid %ux%ux%u lds %zu mode %d\n", a.M, a.NCH, a.N, a.OH, a.OW, a.ncls, pl.MT, pl.NT, pl.WM,
+                2 * pl.CKH, pl.TBU, a.KS, a.BN, a.BH, a.BW, 1 << a.lsh, 1 << a.lsw, pl.grid.x, pl.grid.y, pl.grid.z, pl.lds, mode);
+    rc = launch_pipe(a, pl, st);
+    if (rc) return rc;
+    const int64_t nb = (total + 255) / 256;
+    if (mode == 2) {
+        splitk_reduce_kernel<<<(int)(nb > 4096 ? 4096 : nb), 256, 0, st>>>(ws, out, a.bias, a.KS, total, a.M, HW, a.act,
+                                                                          a.alpha, a.beta);
+        DVF_LAUNCH_CHECK();
+    } else if (mode == 1 && (a.bias || a.act != DVF_ACT_NONE)) {
+        bias_act_kernel<<<(int)(nb > 2048 ? 2048 : nb), 256, 0, st>>>(out, a.bias, a.M, HW, total, a.act, a.alpha, a.beta);
+        DVF_LAUNCH_CHECK();
+    }
+    return DVF_OK;
+}
+
+int pipe_pack(PipeOp &op, const float *w, float *packed, int64_t *nfloats, int64_t *wsfloats, hipStream_t st,
+              PackArgs *job_out = nullptr, int *job_blocks = nullptr) {
+    PipePlan pl;
+    int rc = plan_pipe(op.a, op.cls, op.ncls, pl);
+    if (rc) return rc;
+    if ((size_t)32 * 2 * pl.CKH * op.KK * sizeof(float) > 64 * 1024) return DVF_ERR_UNSUPPORTED;   // pack kernel's LDS tile
+    if (nfloats) *nfloats = pl.packed_floats;
+    if (wsfloats) *wsfloats = op.covers ? pl.ws_floats : 0;
+    if (!w || !packed) return DVF_OK;                       // size query only
+    const PipeArgs &a = op.a;
+    PackArgs p{};
+    p.w = w; p.wp = packed; p.w_mode = op.w_mode; p.Mtot = op.Mtot; p.Rtot = op.Rtot; p.KK = op.KK;
+    p.m_base = op.m_base; p.M = a.M; p.nseg = a.nseg;
+    for (int s = 0; s < a.nseg; ++s) p.segC[s] = a.segC[s];
+    p.ncls = op.ncls; p.NCH = a.NCH; p.CK = 2 * pl.CKH; p.MB = 32 * pl.MT * pl.WM; p.VW = pl.CKH >= 4 ? 4 : pl.CKH;
+    p.TBU = pl.TBU;
+    for (int c = 0; c < op.ncls; ++c) {
+        p.SL[c] = a.cls[c].SL;
+        p.TB[c] = op.cls[c].TB;
+        p.TA[c] = op.cls[c].TA;
+        p.wp_off[c] = a.cls[c].wp_off;
+        for (int t = 0; t < op.cls[c].TA * op.cls[c].TB; ++t) p.tapmap[c][t] = (signed char)op.cls[c].tapmap[t];
+    }
+    const size_t lds = (size_t)32 * p.CK * p.KK * sizeof(float);
+    if (lds > 64 * 1024) return DVF_ERR_UNSUPPORTED;
+    const int mtiles = cdiv(a.M, p.MB) * (p.MB >> 5);
+    if (job_out) {                                          // export for dvf_conv2d_pack_batch instead of launching
+        *job_out = p;
+        *job_blocks = a.NCH * mtiles;
+        return DVF_OK;
+    }
+    conv_pack_kernel<<<dim3(a.NCH, mtiles), 256, lds, st>>>(p);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}

@@ -3,6 +3,7 @@ fp32-MFMA kernels of libdvf_hip.so, the small memory-bound ops around them, and 
 parameter names and shapes equal the reference's (so ``state_dict`` files interchange)."""
 import ctypes
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -26,6 +27,93 @@ def conv_out_size(h, k, stride, pad, opad, transposed):
     return (h - 1) * stride - 2 * pad + k + opad if transposed else (h + 2 * pad - k) // stride + 1
 
 
+_WS = {}      # device -> split-K scratch shared by all convolutions of the main stream
+
+
+def _workspace(nfloats, device):
+    """Scratch for split-K partial tiles.  Forward / dgrad convolutions all run on the current stream, so one buffer
+    per device is enough; it only grows (in the eager warm-up steps, never inside a graph capture)."""
+    buf = _WS.get(device)
+    if buf is None or buf.numel() < nfloats:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        _WS[device] = buf = torch.empty(max(int(nfloats), 1 << 20), device=device, dtype=torch.float32)
+    return buf
+
+
+_PACK_REGISTRY = []    # [weakref(weight), desc, segc, kind, cache entry] of every packed copy in use
+_PACK_TABLE = {"n": -1}
+
+
+def repack_all():
+    """Refresh every packed weight copy with ONE launch (called by FlatAdam.step() right after the update, so the
+    convolutions of the next step find their copies current).  The job table is built once per set of layers."""
+    if not L.USE_PIPE or not _PACK_REGISTRY:
+        return
+    lib = L.lib()
+    live = [(r, r[0]()) for r in _PACK_REGISTRY]
+    live = [(r, w) for r, w in live if w is not None]
+    t = _PACK_TABLE
+    key = tuple((id(r), w.data_ptr()) for r, w in live)
+    if t.get("key") != key:
+        if torch.cuda.is_current_stream_capturing():
+            return                                  # (table changes are picked up by the per-layer path)
+        blobs, blocks, lds = [], [], ctypes.c_int(4)
+        for r, w in live:
+            _, desc, segc, kind, ent = r
+            buf = (ctypes.c_char * (L.PACK_JOB_BYTES * len(segc)))()
+            nb = (ctypes.c_int * len(segc))()
+            n = lib.dvf_conv2d_pack_jobs(ctypes.byref(desc), L.int_array(segc), len(segc), kind, L.dev(w), L.dev(ent[0]),
+                                         ctypes.cast(buf, ctypes.c_void_p), len(segc), nb, ctypes.byref(lds))
+            if n < 0:
+                L.check(n, "dvf_conv2d_pack_jobs")
+            blobs.append(bytes(buf)[: n * L.PACK_JOB_BYTES])
+            blocks += list(nb[:n])
+        dev = live[0][1].device
+        prefix = [0]
+        for b in blocks:
+            prefix.append(prefix[-1] + b)
+        t["jobs"] = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev)
+        t["prefix"] = torch.tensor(prefix, dtype=torch.int32, device=dev)
+        t["njobs"], t["total"], t["lds"], t["key"] = len(blocks), prefix[-1], lds.value, key
+    L.check(lib.dvf_conv2d_pack_batch(t["jobs"].data_ptr(), t["prefix"].data_ptr(), t["njobs"], t["total"], t["lds"],
+                                      L.stream()), "dvf_conv2d_pack_batch")
+    for r, w in live:
+        r[4][1] = (w.data_ptr(), w._version, L.PACK_EPOCH)
+
+
+def _packed_weights(weight, holder, desc, segc, kind):
+    """Packed copy of `weight` for the pipelined kernels (kind 0: forward, 1: dgrad), cached on `holder` (the
+    parameter) per layer geometry and refreshed when the weights changed.  None when the plan is unsupported."""
+    if not L.USE_PIPE:
+        return None, None
+    lib = L.lib()
+    cache = holder.__dict__.setdefault("_dvf_pack", {})
+    key = (kind, desc.N, desc.H_in, desc.W_in, desc.H_out, desc.W_out, desc.stride, desc.pad, desc.transposed, tuple(segc))
+    ent = cache.get(key)
+    if ent is None:
+        nf = lib.dvf_conv2d_packed_floats(ctypes.byref(desc), L.int_array(segc), len(segc), kind)
+        if nf == L.ERR_UNSUPPORTED:
+            cache[key] = ent = [None, None, 0]
+        else:
+            if nf < 0:
+                L.check(int(nf), "dvf_conv2d_packed_floats")
+            # zero-filled once: padding slots of the packed image are never written again
+            wsf = lib.dvf_conv2d_ws_floats(ctypes.byref(desc), L.int_array(segc), len(segc), kind)
+            cache[key] = ent = [torch.zeros(int(nf), device=weight.device, dtype=torch.float32), None, max(int(wsf), 0)]
+            _PACK_REGISTRY.append([weakref.ref(holder), desc, list(segc), kind, ent])
+    buf = ent[0]
+    if buf is None:
+        return None, None
+    stamp = (weight.data_ptr(), weight._version, L.PACK_EPOCH)
+    if ent[1] != stamp:
+        with L.timed("conv_pack", 0.0, 8.0 * weight.numel()):
+            L.check(lib.dvf_conv2d_pack(ctypes.byref(desc), L.int_array(segc), len(segc), kind, L.dev(weight, "weight"),
+                                        L.dev(buf), L.stream()), "dvf_conv2d_pack")
+        ent[1] = stamp
+    return buf, (_workspace(ent[2], weight.device) if ent[2] else None)
+
+
 class ConvFn(torch.autograd.Function):
     """act(conv(cat(inputs), weight) + bias).  cfg = (k, stride, pad, opad, transposed, act, alpha, beta, out_hw)."""
 
@@ -35,6 +123,7 @@ class ConvFn(torch.autograd.Function):
         # parameters owned by a FlatAdam arena: their gradients are added in place (dvf/engine.py)
         ctx.wparam = weight if getattr(weight, "_dvf_grad", None) is not None else None
         ctx.bparam = bias if (bias is not None and getattr(bias, "_dvf_grad", None) is not None) else None
+        ctx.holder = weight
         inputs = [_c(x) for x in inputs]
         weight = _c(weight)
         bias = _c(bias) if bias is not None else None
@@ -56,10 +145,17 @@ class ConvFn(torch.autograd.Function):
         taps = k * k / (stride * stride) if transposed else k * k
         ctx.macs = float(N) * cout * oh * ow * cin * taps
         ctx.tag = f"{'T' if transposed else 'C'}{k}x{k}s{stride} {cin}->{cout} in{H}x{W} out{oh}x{ow} N{N}"
+        packed, ws = _packed_weights(weight, ctx.holder, desc, segc, 0)
         with L.timed("conv_fwd", 2 * ctx.macs, tag=ctx.tag):
-            L.check(L.lib().dvf_conv2d_fwd(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc), len(segc),
-                                           L.dev(weight, "weight"), L.dev(bias, "bias"), L.dev(out), L.stream()),
-                    "dvf_conv2d_fwd")
+            if packed is not None:
+                L.check(L.lib().dvf_conv2d_fwd_packed(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc),
+                                                      len(segc), L.dev(packed), L.dev(bias, "bias"), L.dev(out),
+                                                      L.dev(ws), ws.numel() if ws is not None else 0, L.stream()),
+                        "dvf_conv2d_fwd_packed")
+            else:
+                L.check(L.lib().dvf_conv2d_fwd(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc),
+                                               len(segc), L.dev(weight, "weight"), L.dev(bias, "bias"), L.dev(out),
+                                               L.stream()), "dvf_conv2d_fwd")
         ctx.save_for_backward(weight, out, *inputs)
         ctx.desc, ctx.segc, ctx.has_bias = desc, segc, bias is not None
         return out
@@ -87,9 +183,16 @@ class ConvFn(torch.autograd.Function):
         gins = [torch.empty_like(x) if need else None for x, need in zip(inputs, need_in)]
         if any(need_in):
             frac = sum(c for c, need in zip(segc, need_in) if need) / float(sum(segc))
+            packed, ws = _packed_weights(weight, ctx.holder, desc, segc, 1)
             with L.timed("conv_dgrad", 2 * ctx.macs * frac, tag=ctx.tag):
-                L.check(lib.dvf_conv2d_dgrad(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins),
-                                             L.int_array(segc), len(segc), L.stream()), "dvf_conv2d_dgrad")
+                if packed is not None:
+                    L.check(lib.dvf_conv2d_dgrad_packed(ctypes.byref(desc), L.dev(dpre), L.dev(packed), L.ptr_array(gins),
+                                                        L.int_array(segc), len(segc), L.dev(ws),
+                                                        ws.numel() if ws is not None else 0, L.stream()),
+                            "dvf_conv2d_dgrad_packed")
+                else:
+                    L.check(lib.dvf_conv2d_dgrad(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins),
+                                                 L.int_array(segc), len(segc), L.stream()), "dvf_conv2d_dgrad")
         dw = None
         if need_w:
             arena = ctx.wparam is not None

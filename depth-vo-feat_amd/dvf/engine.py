@@ -171,6 +171,9 @@ class FlatAdam:
                                       self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                       1.0 / self.world_size, L.stream()), "dvf_adam_step")
             first = False
+        L.PACK_EPOCH += 1            # packed convolution weights (dvf/conv.py) are stale now:
+        from . import conv as _conv  # refresh them all with one launch
+        _conv.repack_all()
 
     def set_lr(self, lr):
         self.lr = float(lr)

@@ -57,6 +57,13 @@ SIGNATURES = {
     "dvf_conv2d_fwd": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_fp, c_fp]),
     "dvf_conv2d_dgrad": (c_i, [c_desc, c_fp, c_fp, c_pp, c_ip, c_i, c_fp]),
     "dvf_conv2d_wgrad": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_i, c_fp]),
+    "dvf_conv2d_packed_floats": (c_i64, [c_desc, c_ip, c_i, c_i]),
+    "dvf_conv2d_pack": (c_i, [c_desc, c_ip, c_i, c_i, c_fp, c_fp, c_fp]),
+    "dvf_conv2d_ws_floats": (c_i64, [c_desc, c_ip, c_i, c_i]),
+    "dvf_conv2d_pack_jobs": (c_i, [c_desc, c_ip, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_ip, c_ip]),
+    "dvf_conv2d_pack_batch": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
+    "dvf_conv2d_fwd_packed": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp]),
+    "dvf_conv2d_dgrad_packed": (c_i, [c_desc, c_fp, c_fp, c_pp, c_ip, c_i, c_fp, c_i64, c_fp]),
     "dvf_act_bwd": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_fp]),
     "dvf_resize_bilinear_fwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp]),
     "dvf_upsample2x_bwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_fp]),
@@ -170,6 +177,10 @@ class KernelTimer:
 
 
 TIMER = None    # set to a KernelTimer() to record
+ERR_UNSUPPORTED = -3
+PACK_JOB_BYTES = 512
+PACK_EPOCH = 0  # bumped by FlatAdam.step(): packed copies of the convolution weights are stale after it
+USE_PIPE = os.environ.get("DVF_CONV_PIPE", "1") != "0"   # LDS-DMA pipelined conv kernels over pre-packed weights
 
 
 def timed(kind, flops=0.0, nbytes=0.0, tag=""):

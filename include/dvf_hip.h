@@ -143,6 +143,35 @@ int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, 
 /* d(loss)/d(w) in w's own layout; accumulate != 0 adds to dw, otherwise dw is zeroed first. */
 int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
                      const float *dpre, float *dw, int accumulate, void *stream);
+
+/* Packed-weight fast path: LDS-DMA pipelined kernels that read the weights from a pre-packed copy (the exact LDS
+ * image of every reduction chunk), same results as dvf_conv2d_fwd / dvf_conv2d_dgrad.  op_kind 0 = forward,
+ * 1 = dgrad.  Protocol: n = dvf_conv2d_packed_floats(...) (negative = DVF_ERR_*; DVF_ERR_UNSUPPORTED means "use the
+ * unpacked entry for this geometry"); the caller allocates n floats and ZERO-FILLS them once; dvf_conv2d_pack()
+ * refreshes the copy whenever w changed (after every optimizer step, train.py:214); the *_packed entries consume it.
+ * The packing depends on the whole descriptor (incl. N, H, W) and on seg_channels: use the same ones everywhere. */
+int64_t dvf_conv2d_packed_floats(const dvf_conv_desc *d, const int *seg_channels, int nseg, int op_kind);
+int dvf_conv2d_pack(const dvf_conv_desc *d, const int *seg_channels, int nseg, int op_kind, const float *w, float *packed,
+                    void *stream);
+int dvf_conv2d_fwd_packed(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                          const float *packed, const float *bias, float *out, float *ws, int64_t ws_floats, void *stream);
+int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const float *packed, float *const *din_segs,
+                            const int *seg_channels, int nseg, float *ws, int64_t ws_floats, void *stream);
+/* Optional split-K workspace of the packed entries: with ws (>= dvf_conv2d_ws_floats(...) floats, contents
+ * irrelevant) small grids split the reduction over blocks that store plain partial tiles which one pass reduces
+ * (+bias, activation); with ws == NULL they accumulate with float atomics into a zeroed output instead. */
+int64_t dvf_conv2d_ws_floats(const dvf_conv_desc *d, const int *seg_channels, int nseg, int op_kind);
+/* Batched packing (one launch per optimizer step instead of one per convolution): dvf_conv2d_pack_jobs() writes the
+ * job records of one convolution (1 for op_kind 0, nseg for op_kind 1; DVF_PACK_JOB_BYTES each, opaque) into HOST
+ * memory and their block counts into blocks_out, returning the number of jobs (or a negative DVF_ERR_*).  The caller
+ * concatenates the records of all convolutions, uploads them and the exclusive prefix sum of the block counts
+ * (njobs + 1 ints) to the device once, and calls dvf_conv2d_pack_batch() after every optimizer step with lds_bytes = the
+ * maximum that the pack_jobs calls left in *lds_bytes_out (they only ever raise it). */
+#define DVF_PACK_JOB_BYTES 512
+int dvf_conv2d_pack_jobs(const dvf_conv_desc *d, const int *seg_channels, int nseg, int op_kind, const float *w, float *packed,
+                         void *jobs_host, int max_jobs, int *blocks_out, int *lds_bytes_out);
+int dvf_conv2d_pack_batch(const void *jobs_dev, const int *block_prefix_dev, int njobs, int total_blocks, int lds_bytes,
+                          void *stream);
 /* Backward of the fused activation and of the bias in one pass: dpre = dy * act'(y) (y = the forward's
  * output, [N,C,HW]); dbias[c] = sum dpre (zeroed by the call).  dpre or dbias may be NULL. */
 int dvf_act_bwd(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act,

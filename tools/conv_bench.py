@@ -24,7 +24,7 @@ LAYERS = [  # name, cin segs, cout, k, s, p, op, transposed, act, (N,H,W), out_h
     ("pose up T4x4s2 128->64 ->64x208", [128], 64, 4, 2, 1, 0, True, 1, (4, 32, 104), None),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
-iters = 10
+iters = int(os.environ.get("CB_ITERS", "10"))
 for name, segs, cout, k, s, p, op, tr, act, (n, h, w), ohw in LAYERS:
     if flt not in name:
         continue
