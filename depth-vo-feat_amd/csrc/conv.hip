@@ -325,6 +325,7 @@ constexpr int WG_BW = 32;
 
 template <int MT, int NTW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int COTP = 32 * MT + 1;              // padded row of the transposed P tile (compile-time: immediate offsets)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *qp = smem;                               // [CK][PHq][RS]
     float *pl = smem + a.CK * a.PS;                 // [BH*32 pixels][COTP]
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 for (int k = 0; k < 8; ++k) {
                     const int idx = ib + 4 * k;
                     const int m = idx >> a.lnp, rp = idx - (m << a.lnp);
-                    if (idx < total) pl[((rp * 2 + prow) * WG_BW + px) * a.COTP + m] = v[k];
+                    if (idx < total) pl[((rp * 2 + prow) * WG_BW + px) * COTP + m] = v[k];
                 }
             }
         }
@@ -440,17 +441,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         // ---- MFMA over pixel pairs: groups of 4 steps, the next group's fragments are fetched first
         {
             float af[2][4][MT], bf[2][4][NTW];
+            // one VALU add per group and operand (lane part + scalar group part); steps and m-tiles are immediates.
+            // (a VALU instruction between MFMAs costs 6-8 cycles of matrix-pipe time, LDS and scalar ones none)
+            const float *a_lane = pl + kh * COTP + nl;
+            const float *b_lane[NTW];
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) b_lane[u] = qp + loff[u] + kh;
             auto load = [&](auto bufc, int py, int px0) {
                 constexpr int buf = decltype(bufc)::value;
+                const float *ag = a_lane + (py * WG_BW + px0) * COTP;
+                const int qo = (py * a.S) * a.RS + px0;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int px = px0 + 2 * s4 + kh;
-                    const int p = py * WG_BW + px;
-                    const int qo = (py * a.S) * a.RS + px;
+                for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) af[buf][s4][m] = pl[p * a.COTP + m * 32 + nl];
+                    for (int m = 0; m < MT; ++m) af[buf][s4][m] = ag[2 * s4 * COTP + m * 32];
 #pragma unroll
-                    for (int u = 0; u < NTW; ++u) bf[buf][s4][u] = qp[loff[u] + qo];
+                for (int u = 0; u < NTW; ++u) {
+                    const float *bg = b_lane[u] + qo;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) bf[buf][s4][u] = bg[2 * s4];
                 }
             };
             auto mma = [&](auto bufc) {

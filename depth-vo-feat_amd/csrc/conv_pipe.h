@@ -62,7 +62,7 @@ struct PipeArgs {
     int KS, NCH, out_mode, NG;            // out_mode 0: bias+act store, 1: atomicAdd, 2: plain partial store at ks*ws_slice
     int64_t ws_slice;
     int lsw, lsh, TGX, TGY, BW, BH, BN, tilesX, tilesY;
-    int SLmax, PSRmax;                    // LDS carve per stage: SLmax weight floats | CK * PSRmax patch floats
+    int SLmax, PSRmax, NST;               // LDS carve per stage (NST = 2 or 3 stages): SLmax weight floats | CK * PSRmax patch floats
     int dbg;                              // ablation switches (tools/conv_bench.py): 1 no patch loads, 2 no weight loads, 4 no MFMA
 };
 
@@ -97,10 +97,10 @@ template <> struct fvec<4> { typedef float type __attribute__((ext_vector_type(4
 // taps per unit.  The block has SIX waves: waves 0-3 only read fragments from LDS and issue MFMAs; waves 4 and 5 are
 // producers that issue the LDS-DMA loads of the even / odd chunks (they need no accumulators, so they can hold the
 // per-lane source offset of every patch piece in registers) -- their scalar-heavy bookkeeping issues from their own
-// instruction streams instead of stalling an MFMA wave's.  Three LDS stages: chunk g+2 is issued while chunk g is
-// consumed, and because each producer only ever has ONE chunk in flight, "my chunk has landed" is a plain vmcnt(0).
+// instruction streams instead of stalling an MFMA wave's.  Two or three LDS stages: chunk g+NST-1 is issued
+// while chunk g is consumed, and because each producer only ever has ONE chunk in flight, "my chunk has landed" is a
+// plain vmcnt(0).
 constexpr int PIPE_THREADS = 384;
-constexpr int PIPE_STAGES = 3;
 constexpr int PIPE_MAXNPI = 32;    // patch pieces per channel (per-channel patch <= 2048 floats)
 
 template <int MT, int NT, int WM, int CKH, int TBU>
@@ -215,20 +215,19 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs 
             }
         };
         if (a.dbg & 8) return;
-        if (g_begin + par < g_end) issue(g_begin + par, par);
-        int st = par + 2;                                  // stage of this producer's next chunk (mod PIPE_STAGES)
-        for (int g = g_begin; g < g_end; ++g) {
-            if (((g - g_begin) & 1) == par) {
-                // my chunk g must have landed before anyone passes this barrier; chunk g-1 is fully consumed after it,
-                // which frees the stage chunk g+2 goes to
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (st >= PIPE_STAGES) st -= PIPE_STAGES;
-                if (g + 2 < g_end) issue(g + 2, st);
-                st += 2;
-            } else {
-                __builtin_amdgcn_s_barrier();              // the other producer's chunk: just take part in the barrier
-            }
+        // Chunk x (counted from g_begin) belongs to producer x & 1 and lives in stage x % NST; it is issued NST-1 chunks
+        // ahead.  A producer never has more than one chunk in flight, so "my chunk has landed" is a plain vmcnt(0).
+        const int D = a.NST - 1, nchunks = g_end - g_begin;
+        auto stage_of = [&](int x) { return a.NST == 2 ? (x & 1) : x % 3; };
+        for (int x = 0; x < D; ++x)
+            if (x < nchunks && (x & 1) == par) issue(g_begin + x, stage_of(x));
+        for (int x = 0; x < nchunks; ++x) {
+            // chunk x must have landed before anyone passes this barrier; chunk x-1 is fully consumed after it, which
+            // frees the stage chunk x+D goes to
+            if ((x & 1) == par) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int nx = x + D;
+            if (nx < nchunks && (nx & 1) == par) issue(g_begin + nx, stage_of(nx));
         }
         return;
     }
@@ -237,7 +236,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs 
     const int wm = wave % WM, wn = wave / WM;
     // bias of the block's channels -> LDS (visible after the first chunk barrier): the epilogue must not chain 32
     // dependent global loads
-    float *bias_lds = smem + PIPE_STAGES * stage_floats;
+    float *bias_lds = smem + a.NST * stage_floats;
     if (tid < 32 * MTW) {
         const int mm = mb * (32 * MTW) + tid;
         bias_lds[tid] = (a.bias && a.out_mode == 0 && mm < a.M) ? a.bias[mm] : 0.f;
@@ -366,7 +365,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs 
                 if (a.IS == 2) consume(st, std::integral_constant<int, 2>{});
                 else consume(st, std::integral_constant<int, 1>{});
             }
-            st = (st + 1 == PIPE_STAGES) ? 0 : st + 1;
+            st = (st + 1 == a.NST) ? 0 : st + 1;
         }
     }
 

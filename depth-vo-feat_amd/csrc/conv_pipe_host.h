@@ -165,6 +165,10 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
         OHc = c.OHc > OHc ? c.OHc : OHc; OWc = c.OWc > OWc ? c.OWc : OWc;
     }
     const PipeOverride ov = pipe_override();
+    // Layers with at most 32 output channels have little MFMA work per staged input byte: their patch DMA (4-byte
+    // lanes) saturates the texture-address path before the matrix pipe, and the register-staged conv_gather_kernel is
+    // faster (tools/conv_bench.py, round 1).  They stay on that kernel until the patch is staged in 16-byte lanes.
+    if (a.M <= 32 && !ov.on) return DVF_ERR_UNSUPPORTED;
     int maxc = 0;
     for (int s = 0; s < a.nseg; ++s) maxc = a.segC[s] > maxc ? a.segC[s] : maxc;
     const int64_t px = (int64_t)OHc * OWc;                   // pixels per image per class
@@ -217,16 +221,26 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     a.PSRmax = PSRmax;
     // --- chunk depth: largest CK in {16,8,4} whose two stages fit the LDS budget
     auto slab = [&](int CK, int TA) { return (TA * TBU * CK * MB + 255) & ~255; };
-    auto lds_bytes = [&](int CK) { return ((size_t)dvfp::PIPE_STAGES * (slab(CK, TAmax) + (size_t)CK * PSRmax) + MB) * 4; };
+    int NST = 3;
+    auto lds_bytes = [&](int CK) { return ((size_t)NST * (slab(CK, TAmax) + (size_t)CK * PSRmax) + MB) * 4; };
     // LDS budget: a grid of at most one block per CU may take (nearly) the whole 160 KiB; otherwise leave room for two
     const int KS0 = nblk < 160 ? (int)(256 / nblk) : 1;     // split-K factor before clamping to the chunk count
     const size_t PIPE_LDS_BUDGET = (nblk * KS0 <= 256 ? 150 : 76) * 1024;
     int CK = TBU >= 5 ? 8 : 16;                          // (the 5- and 7-tap kernels are only built for CK <= 8)
     while (CK > 4 && lds_bytes(CK) > PIPE_LDS_BUDGET) CK >>= 1;
     while (CK > 4 && CK / 2 >= maxc) CK >>= 1;
+    if (lds_bytes(CK) > PIPE_LDS_BUDGET) {                   // large kernels (5x5, 7x7): two stages, then one block per CU
+        NST = 2;
+        if (lds_bytes(CK) > PIPE_LDS_BUDGET && PIPE_LDS_BUDGET < 150 * 1024) {
+            NST = 3;
+            if (lds_bytes(CK) > 150 * 1024) NST = 2;
+            if (lds_bytes(CK) > 150 * 1024) return DVF_ERR_UNSUPPORTED;
+        }
+    }
     if (ov.on && ov.CK) CK = ov.CK;
     if (CK != 4 && CK != 8 && CK != 16) return DVF_ERR_UNSUPPORTED;
-    if (lds_bytes(CK) > PIPE_LDS_BUDGET) return DVF_ERR_UNSUPPORTED;
+    if (lds_bytes(CK) > 150 * 1024) return DVF_ERR_UNSUPPORTED;
+    a.NST = NST;
     a.SLmax = slab(CK, TAmax);
     a.NCH = 0;
     for (int s = 0; s < a.nseg; ++s) a.NCH += cdiv(a.segC[s], CK);
@@ -298,8 +312,8 @@ int pipe_run(PipeOp &op, const float *packed, float *ws, int64_t ws_floats, hipS
     if (const char *e = getenv("DVF_DBG")) a.dbg = atoi(e);
     if (getenv("DVF_PIPE_DEBUG"))
         fprintf(stderr, "[pipe] M %d chunks %d N %d out %dx%d cls %d | MT %d NT %d WM %d CK %d TBU %d KS %d BN %d tile %dx%d "
-                "(sub %dx%d) grid %ux%ux%u lds %zu mode %d\n", a.M, a.NCH, a.N, a.OH, a.OW, a.ncls, pl.MT, pl.NT, pl.WM,
-                2 * pl.CKH, pl.TBU, a.KS, a.BN, a.BH, a.BW, 1 << a.lsh, 1 << a.lsw, pl.grid.x, pl.grid.y, pl.grid.z, pl.lds, mode);
+                "(sub %dx%d) grid %ux%ux%u lds %zu x%d mode %d\n", a.M, a.NCH, a.N, a.OH, a.OW, a.ncls, pl.MT, pl.NT, pl.WM,
+                2 * pl.CKH, pl.TBU, a.KS, a.BN, a.BH, a.BW, 1 << a.lsh, 1 << a.lsw, pl.grid.x, pl.grid.y, pl.grid.z, pl.lds, a.NST, mode);
     rc = launch_pipe(a, pl, st);
     if (rc) return rc;
     const int64_t nb = (total + 255) / 256;
