@@ -499,25 +499,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 }
 
 // dpre = dY * act'(Y) and dbias[c] += sum dpre  (one pass; dbias zeroed by the caller side of the ABI)
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float *dy, const float *y, float *dpre, float *dbias, int C,
-                                                      int HW, int act, float alpha, float beta, int chunks) {
+__device__ __forceinline__ float act_grad(float g, float yv, int act, float alpha, float beta) {
+    if (act == DVF_ACT_RELU) return (yv > 0.f) ? g : 0.f;
+    if (act == DVF_ACT_SIGMOID_AFFINE) {
+        const float sg = (yv - beta) / alpha;               // sigmoid value
+        return g * alpha * sg * (1.f - sg);
+    }
+    return g;
+}
+
+// dpre = dy * act'(y) and dbias[c] += sum(dpre) in one pass.  VEC: 16-byte lanes (HW % 4 == 0), 4 independent loads in
+// flight per thread; one atomic per block.
+template <bool VEC>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                      float *__restrict__ dpre, float *dbias, int C, int HW, int act,
+                                                      float alpha, float beta, int chunks) {
     __shared__ float red[4];
     const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
     const int c = plane % C;
-    const int per = (HW + chunks - 1) / chunks;
-    const int beg = chunk * per, end = min(HW, beg + per);
     const int64_t base = (int64_t)plane * HW;
     float s = 0.f;
-    for (int i = beg + threadIdx.x; i < end; i += 256) {
-        float g = dy[base + i];
-        if (act == DVF_ACT_RELU) {
-            g = (y[base + i] > 0.f) ? g : 0.f;
-        } else if (act == DVF_ACT_SIGMOID_AFFINE) {
-            const float sg = (y[base + i] - beta) / alpha;      // sigmoid value
-            g = g * alpha * sg * (1.f - sg);
+    if (VEC) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int HW4 = HW >> 2, per = (HW4 + chunks - 1) / chunks;
+        const int beg = chunk * per, end = min(HW4, beg + per);
+        const f4 *dy4 = reinterpret_cast<const f4 *>(dy + base), *y4 = reinterpret_cast<const f4 *>(y ? y + base : dy + base);
+        f4 *o4 = reinterpret_cast<f4 *>(dpre ? dpre + base : nullptr);
+        for (int i0 = beg + threadIdx.x; i0 < end; i0 += 1024) {
+            f4 g[4], yv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + 256 * k;
+                if (i < end) { g[k] = dy4[i]; yv[k] = (act != DVF_ACT_NONE) ? y4[i] : g[k]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + 256 * k;
+                if (i < end) {
+                    f4 r;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { r[e] = act_grad(g[k][e], yv[k][e], act, alpha, beta); s += r[e]; }
+                    if (dpre) o4[i] = r;
+                }
+            }
         }
-        if (dpre) dpre[base + i] = g;
-        s += g;
+    } else {
+        const int per = (HW + chunks - 1) / chunks;
+        const int beg = chunk * per, end = min(HW, beg + per);
+        for (int i = beg + threadIdx.x; i < end; i += 256) {
+            const float g = act_grad(dy[base + i], (act != DVF_ACT_NONE) ? y[base + i] : 0.f, act, alpha, beta);
+            if (dpre) dpre[base + i] = g;
+            s += g;
+        }
     }
     if (dbias) {
         s = wave_sum(s);
@@ -903,20 +936,28 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
     return DVF_OK;
 }
 
-int dvf_act_bwd(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act, float alpha,
-                float beta, void *stream) {
+int dvf_act_bwd2(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act, float alpha,
+                 float beta, int accumulate_dbias, void *stream) {
     if (!dy || (act != DVF_ACT_NONE && !y) || N <= 0 || C <= 0 || HW <= 0) return DVF_ERR_INVALID_ARG;
     if (!dpre && !dbias) return DVF_OK;
     hipStream_t st = dvf_stream(stream);
-    if (dbias && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) return DVF_ERR_LAUNCH;
-    int chunks = (HW + 4095) / 4096;
+    if (dbias && !accumulate_dbias && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) return DVF_ERR_LAUNCH;
+    const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) |
+                                        reinterpret_cast<uintptr_t>(dpre)) % 16 == 0);
+    int chunks = (HW + 8191) / 8192;
     const int64_t planes = (int64_t)N * C;
     while (chunks > 1 && planes * chunks > 16384) chunks >>= 1;
-    act_bwd_kernel<<<(unsigned)(planes * chunks), 256, 0, st>>>(dy, y, dpre, dbias, C, HW, act, alpha, beta, chunks);
+    while (planes * chunks < 1024 && HW / (chunks * 2) >= 1024) chunks *= 2;    // small layers: still fill the GPU
+    if (vec) act_bwd_kernel<true><<<(unsigned)(planes * chunks), 256, 0, st>>>(dy, y, dpre, dbias, C, HW, act, alpha, beta, chunks);
+    else act_bwd_kernel<false><<<(unsigned)(planes * chunks), 256, 0, st>>>(dy, y, dpre, dbias, C, HW, act, alpha, beta, chunks);
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }
 
+int dvf_act_bwd(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act, float alpha,
+                float beta, void *stream) {
+    return dvf_act_bwd2(dy, y, dpre, dbias, N, C, HW, act, alpha, beta, 0, stream);
+}
 
 }  // extern "C"
 

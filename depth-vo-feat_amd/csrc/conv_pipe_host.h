@@ -116,11 +116,11 @@ struct PipePlan {
     int64_t packed_floats, ws_floats;
 };
 
-struct PipeOverride { int on, MT, NT, WM, CK, KS, BN, TBU; };
+struct PipeOverride { int on, MT, NT, WM, CK, KS, BN, NST; };
 inline PipeOverride pipe_override() {
     PipeOverride o{0, 0, 0, 0, 0, 0, 0, 0};
-    if (const char *e = getenv("DVF_PIPE_PLAN"))         // "MT,NT,WM,CK,KS,BN,TBU" (0 = automatic) -- tuning tool only
-        if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &o.MT, &o.NT, &o.WM, &o.CK, &o.KS, &o.BN, &o.TBU) >= 1) o.on = 1;
+    if (const char *e = getenv("DVF_PIPE_PLAN"))         // "MT,NT,WM,CK,KS,BN,NST" (0 = automatic) -- tuning tool only
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &o.MT, &o.NT, &o.WM, &o.CK, &o.KS, &o.BN, &o.NST) >= 1) o.on = 1;
     return o;
 }
 
@@ -169,6 +169,7 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     // lanes) saturates the texture-address path before the matrix pipe, and the register-staged conv_gather_kernel is
     // faster (tools/conv_bench.py, round 1).  They stay on that kernel until the patch is staged in 16-byte lanes.
     if (a.M <= 32 && !ov.on) return DVF_ERR_UNSUPPORTED;
+    if (ov.on && ov.KS < 0) return DVF_ERR_UNSUPPORTED;      // (tuning: force the gather kernel)
     int maxc = 0;
     for (int s = 0; s < a.nseg; ++s) maxc = a.segC[s] > maxc ? a.segC[s] : maxc;
     const int64_t px = (int64_t)OHc * OWc;                   // pixels per image per class
@@ -237,7 +238,8 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
             if (lds_bytes(CK) > 150 * 1024) return DVF_ERR_UNSUPPORTED;
         }
     }
-    if (ov.on && ov.CK) CK = ov.CK;
+    if (ov.on && ov.CK) { CK = ov.CK; NST = 3; if (lds_bytes(CK) > 150 * 1024) NST = 2; }
+    if (ov.on && ov.NST) NST = ov.NST;
     if (CK != 4 && CK != 8 && CK != 16) return DVF_ERR_UNSUPPORTED;
     if (lds_bytes(CK) > 150 * 1024) return DVF_ERR_UNSUPPORTED;
     a.NST = NST;

@@ -27,17 +27,18 @@ def conv_out_size(h, k, stride, pad, opad, transposed):
     return (h - 1) * stride - 2 * pad + k + opad if transposed else (h + 2 * pad - k) // stride + 1
 
 
-_WS = {}      # device -> split-K scratch shared by all convolutions of the main stream
+_WS = {}      # (device, stream) -> split-K scratch shared by the convolutions of that stream
 
 
 def _workspace(nfloats, device):
-    """Scratch for split-K partial tiles.  Forward / dgrad convolutions all run on the current stream, so one buffer
-    per device is enough; it only grows (in the eager warm-up steps, never inside a graph capture)."""
-    buf = _WS.get(device)
+    """Scratch for split-K partial tiles: one buffer per compute stream (kernels of one stream are ordered, so they can
+    share it); it only grows (in the eager warm-up steps, never inside a graph capture)."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
         if torch.cuda.is_current_stream_capturing():
             return None
-        _WS[device] = buf = torch.empty(max(int(nfloats), 1 << 20), device=device, dtype=torch.float32)
+        _WS[key] = buf = torch.empty(max(int(nfloats), 1 << 20), device=device, dtype=torch.float32)
     return buf
 
 
@@ -169,17 +170,19 @@ class ConvFn(torch.autograd.Function):
         N, cout, oh, ow = out.shape
         need_w, need_b = ctx.needs_input_grad[0], ctx.has_bias and ctx.needs_input_grad[1]
         need_in = list(ctx.needs_input_grad[3:])
-        dbias = torch.empty(cout, device=out.device) if need_b else None
+        # a bias owned by a FlatAdam arena: its gradient slice is zero after zero_grad(), add the channel sums in place
+        acc_b = need_b and ctx.bparam is not None
+        dbias = (ctx.bparam._dvf_grad if acc_b else torch.empty(cout, device=out.device)) if need_b else None
         if desc.act != L.ACT_NONE:
             dpre = torch.empty_like(gout)
             with L.timed("act_bwd", 0.0, 12.0 * gout.numel()):
-                L.check(lib.dvf_act_bwd(L.dev(gout, "grad_out"), L.dev(out), L.dev(dpre), L.dev(dbias), N, cout, oh * ow,
-                                        desc.act, desc.alpha, desc.beta, L.stream()), "dvf_act_bwd")
+                L.check(lib.dvf_act_bwd2(L.dev(gout, "grad_out"), L.dev(out), L.dev(dpre), L.dev(dbias), N, cout, oh * ow,
+                                         desc.act, desc.alpha, desc.beta, 1 if acc_b else 0, L.stream()), "dvf_act_bwd2")
         else:
             dpre = gout
             if need_b:
-                L.check(lib.dvf_act_bwd(L.dev(gout), None, None, L.dev(dbias), N, cout, oh * ow, L.ACT_NONE, 1.0, 0.0,
-                                        L.stream()), "dvf_act_bwd")
+                L.check(lib.dvf_act_bwd2(L.dev(gout), None, None, L.dev(dbias), N, cout, oh * ow, L.ACT_NONE, 1.0, 0.0,
+                                         1 if acc_b else 0, L.stream()), "dvf_act_bwd2")
         gins = [torch.empty_like(x) if need else None for x, need in zip(inputs, need_in)]
         if any(need_in):
             frac = sum(c for c, need in zip(segc, need_in) if need) / float(sum(segc))
@@ -207,8 +210,7 @@ class ConvFn(torch.autograd.Function):
             if arena:
                 ctx.wparam._dvf_owner.grad_ready(ctx.wparam)
                 dw = None
-        if need_b and ctx.bparam is not None:
-            ctx.bparam._dvf_grad.add_(dbias)
+        if acc_b:
             ctx.bparam._dvf_owner.grad_ready(ctx.bparam)
             dbias = None
         return (dw, dbias, None, *gins)

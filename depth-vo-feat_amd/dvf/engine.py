@@ -126,10 +126,14 @@ class FlatAdam:
             self._comm_stream.wait_event(ev)
             if self._side_dirty:
                 self._comm_stream.wait_stream(self.side)      # the bucket's weight gradients come from the side stream
+            for dev, aux in L.AUX_STREAMS.items():            # ... or from a sub-network on the auxiliary stream
+                if dev == self._comm_stream.device:
+                    self._comm_stream.wait_stream(aux)
             dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
 
     # ------------------------------------------------------------------ optimizer API
     def zero_grad(self):
+        L.join_aux_streams()
         self.join_wgrad()
         self.flat_g.zero_()
         self._reset_pending()
@@ -161,6 +165,7 @@ class FlatAdam:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
 
     def step(self):
+        L.join_aux_streams()         # backward kernels of a sub-network that ran on the auxiliary stream
         self.join_wgrad()
         self.synchronize_grads()
         lib = L.lib()

@@ -65,6 +65,7 @@ SIGNATURES = {
     "dvf_conv2d_fwd_packed": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp]),
     "dvf_conv2d_dgrad_packed": (c_i, [c_desc, c_fp, c_fp, c_pp, c_ip, c_i, c_fp, c_i64, c_fp]),
     "dvf_act_bwd": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_fp]),
+    "dvf_act_bwd2": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_i, c_fp]),
     "dvf_resize_bilinear_fwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp]),
     "dvf_upsample2x_bwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_fp]),
     "dvf_recip_fwd": (c_i, [c_fp, c_fp, c_f, c_i64, c_fp]),
@@ -179,6 +180,24 @@ class KernelTimer:
 TIMER = None    # set to a KernelTimer() to record
 ERR_UNSUPPORTED = -3
 PACK_JOB_BYTES = 512
+AUX_STREAMS = {}      # device -> auxiliary compute stream (dvf/steps.py runs the pose network on it)
+
+
+def aux_stream(device):
+    s = AUX_STREAMS.get(device)
+    if s is None:
+        AUX_STREAMS[device] = s = torch.cuda.Stream(device=device)
+    return s
+
+
+def join_aux_streams():
+    """Make the current stream wait for everything enqueued on the auxiliary compute streams."""
+    cur = torch.cuda.current_stream()
+    for dev, s in AUX_STREAMS.items():
+        if dev == cur.device:
+            cur.wait_stream(s)
+
+
 PACK_EPOCH = 0  # bumped by FlatAdam.step(): packed copies of the convolution weights are stale after it
 USE_PIPE = os.environ.get("DVF_CONV_PIPE", "1") != "0"   # LDS-DMA pipelined conv kernels over pre-packed weights
 

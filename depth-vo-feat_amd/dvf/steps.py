@@ -4,18 +4,47 @@
   train_sfm_losses    train.py:179-203        4-scale photometric with masks + w3*smooth + stereo-pose MSE
 Each returns (total_loss, dict of detached per-term losses); the caller does zero_grad / backward / step.
 No ``.item()`` here: the reference's 5 host syncs per step (train.py:205-209) are left to the logger."""
+import os
+
 import torch
 
 import loss_functions as LF
 import loss_functions_sfm as LS
+from dvf import lib as L
 from dvf.conv import reciprocal
+
+
+def _side_by_side(aux_fn, main_fn):
+    """Run two independent sub-networks concurrently: ``aux_fn`` (the small pose network) on a second stream, ``main_fn``
+    (the depth network) on the current one.  The deep layers of either network launch fewer blocks than the GPU has
+    CUs, so the two fill each other's gaps; autograd runs each backward on its forward stream, so the backward passes
+    overlap too.  FlatAdam.step() joins the auxiliary stream (dvf/lib.py AUX_STREAMS).  DVF_POSE_STREAM=0 disables."""
+    if os.environ.get("DVF_POSE_STREAM", "1") == "0":
+        return aux_fn(), main_fn()
+    cur = torch.cuda.current_stream()
+    aux = L.aux_stream(cur.device)
+    aux.wait_stream(cur)
+    with torch.cuda.stream(aux):
+        a_out = aux_fn()
+    m_out = main_fn()
+    cur.wait_stream(aux)
+
+    def _mark(t):
+        if torch.is_tensor(t):
+            t.record_stream(cur)          # produced on aux, consumed by the losses on the current stream
+        elif isinstance(t, (list, tuple)):
+            for x in t:
+                _mark(x)
+    _mark(a_out)
+    return a_out, m_out
 
 
 def unsupervise_losses(depth_net, pose_net, batch, feat_extractor=None, img_scale=0.004, smooth_weight=10.0,
                        feat_weight=0.1, depth_eps=1e-4):
     R2, R1, L2 = batch["img_R2"], batch["img_R1"], batch["img_L2"]
-    inv_depth = depth_net(R2)[0]                                   # unsupervise.py:94 (intended: finest disparity)
-    _, T_2to1 = pose_net((R2, R1))                                 # :92,95   cat(R2, R1) done virtually
+    # unsupervise.py:92,95 (cat(R2, R1) done virtually) and :94 (intended: finest disparity)
+    (_, T_2to1), disps = _side_by_side(lambda: pose_net((R2, R1)), lambda: depth_net(R2))
+    inv_depth = disps[0]
     depth = reciprocal(inv_depth, depth_eps).squeeze(1)            # :99
     img_loss = LF.photometric_reconstruction_loss(img_scale * R2, img_scale * R1, img_scale * L2, depth, T_2to1,
                                                   batch["T_R2L"], batch["K"], batch["Kinv"])       # :101
@@ -38,9 +67,8 @@ def train_sfm_losses(disp_net, pose_exp_net, batch, w1=1.0, w2=0.0, w3=0.1, smoo
                      rotation_mode="euler", padding_mode="zeros"):
     tgt = batch["img_R2"]
     refs = [batch["img_R1"], batch["img_L2"]] + list(batch.get("extra_refs", []))[: pose_exp_net.nb_ref_imgs - 2]
-    disparities = disp_net(tgt)                                    # train.py:187
+    (masks, pose), disparities = _side_by_side(lambda: pose_exp_net(tgt, refs), lambda: disp_net(tgt))   # train.py:187,189
     depth = [reciprocal(d, 0.0) for d in disparities]              # :188
-    masks, pose = pose_exp_net(tgt, refs)                          # :189
     l1 = LS.photometric_reconstruction_loss(tgt, refs, batch["K"], batch["Kinv"], depth, masks, pose,
                                             rotation_mode, padding_mode)                           # :191
     l3 = LS.smooth_loss(depth, smooth_factor)                      # :200
@@ -61,11 +89,10 @@ def unsupervise_dvo_losses(depth_net, pose_net, batch, img_scale=0.004, smooth_w
     stereo (L2 -> R2) and temporal (R1 -> R2) warps + 10 * smooth(depth).  All of it is the fused warp kernel with the
     DVF_POSE_SE3 | DVF_PIXEL_COORDS front end.  batch["T_R2L"] must be in the se(3) order (w, u), i.e. (0,0,0,Tx,0,0)
     as the reference dataset writes it (data/dataset_builder.py:155)."""
-    from dvf import lib as L
     from dvf.ops import PhotoLossFn
     R2, R1, L2 = batch["img_R2"], batch["img_R1"], batch["img_L2"]
-    inv_depth = depth_net(R2)[0]
-    _, T_2to1 = pose_net((R2, R1))
+    (_, T_2to1), disps = _side_by_side(lambda: pose_net((R2, R1)), lambda: depth_net(R2))
+    inv_depth = disps[0]
     depth = reciprocal(inv_depth, depth_eps)                               # [B,1,H,W]
     pose = torch.stack((batch["T_R2L"], T_2to1), dim=0)                    # [V=2,B,6]: view 0 = left image, view 1 = R1
     photo = PhotoLossFn.apply(img_scale * R2, depth.squeeze(1), pose, batch["K"], batch["Kinv"], None,

@@ -176,6 +176,10 @@ int dvf_conv2d_pack_batch(const void *jobs_dev, const int *block_prefix_dev, int
  * output, [N,C,HW]); dbias[c] = sum dpre (zeroed by the call).  dpre or dbias may be NULL. */
 int dvf_act_bwd(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act,
                 float alpha, float beta, void *stream);
+/* Same, with accumulate_dbias != 0: dbias is NOT zeroed first, the channel sums are added to it (a bias gradient that
+ * lives in a zeroed gradient arena needs neither a memset nor a separate add). */
+int dvf_act_bwd2(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act, float alpha,
+                 float beta, int accumulate_dbias, void *stream);
 
 /* ---------------------------------------------------------------- memory-bound helpers
  * planes = N*C throughout. */
