@@ -192,6 +192,8 @@ def aux_stream(device):
 
 def join_aux_streams():
     """Make the current stream wait for everything enqueued on the auxiliary compute streams."""
+    if not AUX_STREAMS:
+        return
     cur = torch.cuda.current_stream()
     for dev, s in AUX_STREAMS.items():
         if dev == cur.device:
