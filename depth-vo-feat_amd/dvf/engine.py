@@ -80,7 +80,7 @@ class FlatAdam:
     def fork_wgrad(self, *tensors):
         """Make the side stream wait for everything enqueued so far on the current stream; returns the side stream
         (or None: run on the current stream).  ``tensors`` are kept alive until ``join_wgrad``."""
-        if self.side is None:
+        if self.side is None or L.SERIALIZE:
             return None
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())

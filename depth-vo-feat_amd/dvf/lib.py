@@ -180,6 +180,7 @@ class KernelTimer:
 TIMER = None    # set to a KernelTimer() to record
 ERR_UNSUPPORTED = -3
 PACK_JOB_BYTES = 512
+SERIALIZE = os.environ.get("DVF_SERIALIZE", "0") == "1"   # True: no side streams (per-kernel timing passes, debugging)
 AUX_STREAMS = {}      # device -> auxiliary compute stream (dvf/steps.py runs the pose network on it)
 
 

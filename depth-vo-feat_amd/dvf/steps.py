@@ -19,7 +19,7 @@ def _side_by_side(aux_fn, main_fn):
     (the depth network) on the current one.  The deep layers of either network launch fewer blocks than the GPU has
     CUs, so the two fill each other's gaps; autograd runs each backward on its forward stream, so the backward passes
     overlap too.  FlatAdam.step() joins the auxiliary stream (dvf/lib.py AUX_STREAMS).  DVF_POSE_STREAM=0 disables."""
-    if os.environ.get("DVF_POSE_STREAM", "1") == "0":
+    if L.SERIALIZE or os.environ.get("DVF_POSE_STREAM", "1") == "0":
         return aux_fn(), main_fn()
     cur = torch.cuda.current_stream()
     aux = L.aux_stream(cur.device)
