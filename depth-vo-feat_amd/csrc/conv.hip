@@ -20,6 +20,7 @@
 #include "dvf_common.h"
 #include <string.h>
 #include "conv_pipe.h"
+#include "conv_head.h"
 
 namespace {
 
@@ -802,6 +803,10 @@ int dvf_conv2d_fwd(const dvf_conv_desc *d, const float *const *in_segs, const in
     rc = check_segs(d, seg_channels, nseg);
     if (rc) return rc;
     if (!in_segs || !w || !out) return DVF_ERR_INVALID_ARG;
+    if (dvf_head_applicable(d, nseg)) {
+        if (!in_segs[0]) return DVF_ERR_INVALID_ARG;
+        return dvf_head_fwd(d, in_segs[0], w, bias, out, dvf_stream(stream));
+    }
     GatherArgs a{};
     for (int s = 0; s < nseg; ++s) {
         if (!in_segs[s]) return DVF_ERR_INVALID_ARG;
@@ -834,6 +839,7 @@ int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, 
     rc = check_segs(d, seg_channels, nseg);
     if (rc) return rc;
     if (!dpre || !w || !din_segs) return DVF_ERR_INVALID_ARG;
+    if (dvf_head_applicable(d, nseg)) return din_segs[0] ? dvf_head_dgrad(d, dpre, w, din_segs[0], dvf_stream(stream)) : DVF_OK;
     int off = 0;
     for (int s = 0; s < nseg; ++s) {
         const int segc = seg_channels[s];
@@ -873,6 +879,10 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
     if (rc) return rc;
     if (!in_segs || !dpre || !dw) return DVF_ERR_INVALID_ARG;
     hipStream_t st = dvf_stream(stream);
+    if (dvf_head_applicable(d, nseg)) {
+        if (!in_segs[0]) return DVF_ERR_INVALID_ARG;
+        return dvf_head_wgrad(d, in_segs[0], dpre, dw, accumulate, st);
+    }
     const int KK = d->KH * d->KW;
     if (!accumulate &&
         hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->C_in * d->C_out * KK, st) != hipSuccess)

@@ -1,0 +1,7 @@
+// Direct kernels for 1-4 channel 3x3 heads (conv_head.hip), dispatched from the dvf_conv2d_* entries.
+#pragma once
+#include "dvf_common.h"
+bool dvf_head_applicable(const dvf_conv_desc *d, int nseg);
+int dvf_head_fwd(const dvf_conv_desc *d, const float *in, const float *w, const float *bias, float *out, hipStream_t st);
+int dvf_head_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, hipStream_t st);
+int dvf_head_wgrad(const dvf_conv_desc *d, const float *in, const float *dpre, float *dw, int accumulate, hipStream_t st);

@@ -1,0 +1,206 @@
+// Direct (non-MFMA) kernels for the 1-4 channel 3x3 prediction heads (predict_disp*, DispNetS.py:66-69; the
+// explainability-mask heads, PoseExpNet_sfm.py:43-46).  A 32-row MFMA tile would be 88-97 % padding for these
+// layers; they are memory-bound (read the C_in-channel activation once), so plain FMAs over an LDS-staged tile are
+// the right tool: forward, dgrad and wgrad.  3x3, stride 1, padding 1, single input segment, C_out <= 4.
+#include "conv_head.h"
+
+namespace {
+
+constexpr int HT_W = 64, HT_H = 4;          // pixel tile per block (256 threads, one pixel each)
+constexpr int HP_W = HT_W + 2, HP_H = HT_H + 2;
+constexpr int HCK = 8;                      // input channels staged per pass (forward)
+constexpr int HWK = 7;                      // ... in wgrad: 7 channels x 9 taps = 63 columns, one per lane
+
+__device__ __forceinline__ float head_act(float v, int act, float alpha, float beta) {
+    if (act == DVF_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == DVF_ACT_SIGMOID_AFFINE) return alpha * (1.f / (1.f + expf(-v))) + beta;
+    return v;
+}
+
+// stage `nch` channel planes (tile + halo 1, zero outside the image) into lds[ch][HP_H][HP_W]
+__device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__ src, int64_t plane, int nch, int H, int W,
+                                           int y0, int x0) {
+    for (int e = threadIdx.x; e < nch * HP_H * HP_W; e += 256) {
+        const int ch = e / (HP_H * HP_W), r = e - ch * (HP_H * HP_W), py = r / HP_W, px = r - py * HP_W;
+        const int y = y0 + py - 1, x = x0 + px - 1;
+        lds[e] = (y >= 0 && y < H && x >= 0 && x < W) ? src[ch * plane + (int64_t)y * W + x] : 0.f;
+    }
+}
+
+// out[n][mo][y][x] = act(b[mo] + sum_c sum_taps w[mo][c][tap] * in[n][c][y+ta-1][x+tb-1])
+template <int MO>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                       const float *__restrict__ bias, float *__restrict__ out, int C, int H,
+                                                       int W, int tilesX, int act, float alpha, float beta) {
+    __shared__ float tile[HCK * HP_H * HP_W];
+    const int n = blockIdx.y, tY = blockIdx.x / tilesX, tX = blockIdx.x - tY * tilesX;
+    const int y0 = tY * HT_H, x0 = tX * HT_W;
+    const int lx = threadIdx.x & (HT_W - 1), ly = threadIdx.x >> 6;
+    const int64_t plane = (int64_t)H * W;
+    float acc[MO];
+#pragma unroll
+    for (int m = 0; m < MO; ++m) acc[m] = bias ? bias[m] : 0.f;
+    for (int c0 = 0; c0 < C; c0 += HCK) {
+        const int nch = min(HCK, C - c0);
+        __syncthreads();
+        stage_tile(tile, in + ((int64_t)n * C + c0) * plane, plane, nch, H, W, y0, x0);
+        __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {
+            const float *t = tile + ch * (HP_H * HP_W) + ly * HP_W + lx;
+            float v[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) v[a * 3 + b] = t[a * HP_W + b];
+#pragma unroll
+            for (int m = 0; m < MO; ++m) {
+                const float *wm = w + ((int64_t)m * C + c0 + ch) * 9;        // uniform address: scalar loads
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[m] = fmaf(wm[k], v[k], acc[m]);
+            }
+        }
+    }
+    const int y = y0 + ly, x = x0 + lx;
+    if (y < H && x < W) {
+#pragma unroll
+        for (int m = 0; m < MO; ++m) out[((int64_t)n * MO + m) * plane + (int64_t)y * W + x] = head_act(acc[m], act, alpha, beta);
+    }
+}
+
+// din[n][c][y][x] = sum_mo sum_taps w[mo][c][ta][tb] * dpre[n][mo][y-ta+1][x-tb+1]
+template <int MO>
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float *__restrict__ dpre, const float *__restrict__ w,
+                                                         float *__restrict__ din, int C, int H, int W, int tilesX) {
+    __shared__ float tile[MO * HP_H * HP_W];
+    const int n = blockIdx.y, tY = blockIdx.x / tilesX, tX = blockIdx.x - tY * tilesX;
+    const int y0 = tY * HT_H, x0 = tX * HT_W;
+    const int lx = threadIdx.x & (HT_W - 1), ly = threadIdx.x >> 6;
+    const int64_t plane = (int64_t)H * W;
+    stage_tile(tile, dpre + (int64_t)n * MO * plane, plane, MO, H, W, y0, x0);
+    __syncthreads();
+    float g[MO][9];                          // g[mo][ta*3+tb] = dpre[mo][y-ta+1][x-tb+1]
+#pragma unroll
+    for (int m = 0; m < MO; ++m)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[m][a * 3 + b] = tile[m * (HP_H * HP_W) + (ly + 2 - a) * HP_W + (lx + 2 - b)];
+    const int y = y0 + ly, x = x0 + lx;
+    if (y >= H || x >= W) return;
+    float *dst = din + (int64_t)n * C * plane + (int64_t)y * W + x;
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < MO; ++m) {
+            const float *wm = w + ((int64_t)m * C + c) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s = fmaf(wm[k], g[m][k], s);
+        }
+        dst[c * plane] = s;
+    }
+}
+
+// dW[mo][c][ta][tb] (+)= sum_{n,y,x} dpre[n][mo][y][x] * in[n][c][y+ta-1][x+tb-1]
+// grid (channel chunks of HWK, pixel-tile groups); thread t < nch*9 owns column (c, tap) and walks the tile's pixels
+template <int MO>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float *__restrict__ in, const float *__restrict__ dpre,
+                                                         float *dw, int N, int C, int H, int W, int tilesX, int tilesY) {
+    __shared__ float tin[HWK * HP_H * HP_W];
+    __shared__ float tdp[MO * HT_H * HT_W];
+    __shared__ float red[4 * HWK * 9 * MO];
+    const int c0 = blockIdx.x * HWK, nch = min(HWK, C - c0);
+    const int64_t plane = (int64_t)H * W;
+    // 4 waves split the tile's rows; lane < nch*9 owns one (c, tap) column
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col_c = lane / 9, col_t = lane - col_c * 9, ta = col_t / 3, tb = col_t - ta * 3;
+    const bool active = lane < nch * 9;
+    float acc[MO];
+#pragma unroll
+    for (int m = 0; m < MO; ++m) acc[m] = 0.f;
+    const int ntiles = N * tilesX * tilesY;
+    for (int tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
+        const int n = tile / (tilesX * tilesY), r = tile - n * (tilesX * tilesY), tY = r / tilesX, tX = r - tY * tilesX;
+        const int y0 = tY * HT_H, x0 = tX * HT_W;
+        __syncthreads();
+        stage_tile(tin, in + ((int64_t)n * C + c0) * plane, plane, nch, H, W, y0, x0);
+        for (int e = threadIdx.x; e < MO * HT_H * HT_W; e += 256) {
+            const int m = e / (HT_H * HT_W), q = e - m * (HT_H * HT_W), py = q / HT_W, px = q - py * HT_W;
+            const int y = y0 + py, x = x0 + px;
+            tdp[e] = (y < H && x < W) ? dpre[((int64_t)n * MO + m) * plane + (int64_t)y * W + x] : 0.f;
+        }
+        __syncthreads();
+        if (active) {
+            const float *src = tin + col_c * (HP_H * HP_W) + (wave + ta) * HP_W + tb;      // row `wave` of the tile
+            const float *dp = tdp + wave * HT_W;
+#pragma unroll 8
+            for (int px = 0; px < HT_W; ++px) {
+                const float v = src[px];
+#pragma unroll
+                for (int m = 0; m < MO; ++m) acc[m] = fmaf(dp[m * (HT_H * HT_W) + px], v, acc[m]);     // broadcast reads
+            }
+        }
+    }
+    // combine the 4 waves, one atomic per output
+    if (active)
+#pragma unroll
+        for (int m = 0; m < MO; ++m) red[(wave * MO + m) * (HWK * 9) + lane] = acc[m];
+    __syncthreads();
+    if (wave == 0 && active) {
+#pragma unroll
+        for (int m = 0; m < MO; ++m) {
+            const float s = (red[(0 * MO + m) * (HWK * 9) + lane] + red[(1 * MO + m) * (HWK * 9) + lane]) +
+                            (red[(2 * MO + m) * (HWK * 9) + lane] + red[(3 * MO + m) * (HWK * 9) + lane]);
+            atomicAdd(&dw[((int64_t)m * C + c0 + col_c) * 9 + col_t], s);
+        }
+    }
+}
+
+inline int cdivh(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+bool dvf_head_applicable(const dvf_conv_desc *d, int nseg) {
+    return nseg == 1 && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->C_out >= 1 &&
+           d->C_out <= 4 && d->H_out == d->H_in && d->W_out == d->W_in && d->C_in >= 4 && getenv("DVF_NO_HEAD") == nullptr;
+}
+
+#define HEAD_DISPATCH(MOV, CALL)                 \
+    switch (MOV) {                               \
+        case 1: { constexpr int MO = 1; CALL; } break; \
+        case 2: { constexpr int MO = 2; CALL; } break; \
+        case 3: { constexpr int MO = 3; CALL; } break; \
+        case 4: { constexpr int MO = 4; CALL; } break; \
+        default: return DVF_ERR_UNSUPPORTED;     \
+    }
+
+int dvf_head_fwd(const dvf_conv_desc *d, const float *in, const float *w, const float *bias, float *out, hipStream_t st) {
+    const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, HT_H);
+    const dim3 grid(tilesX * tilesY, d->N);
+    HEAD_DISPATCH(d->C_out, (head_fwd_kernel<MO><<<grid, 256, 0, st>>>(in, w, bias, out, d->C_in, d->H_in, d->W_in, tilesX,
+                                                                      d->act, d->alpha, d->beta)));
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+int dvf_head_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, hipStream_t st) {
+    const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, HT_H);
+    const dim3 grid(tilesX * tilesY, d->N);
+    HEAD_DISPATCH(d->C_out, (head_dgrad_kernel<MO><<<grid, 256, 0, st>>>(dpre, w, din, d->C_in, d->H_in, d->W_in, tilesX)));
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+int dvf_head_wgrad(const dvf_conv_desc *d, const float *in, const float *dpre, float *dw, int accumulate, hipStream_t st) {
+    if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->C_out * d->C_in * 9, st) != hipSuccess)
+        return DVF_ERR_LAUNCH;
+    const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, HT_H);
+    const int chunks = cdivh(d->C_in, HWK), ntiles = d->N * tilesX * tilesY;
+    int groups = 2048 / chunks;
+    if (groups < 1) groups = 1;
+    if (groups > ntiles) groups = ntiles;
+    const dim3 grid(chunks, groups);
+    HEAD_DISPATCH(d->C_out, (head_wgrad_kernel<MO><<<grid, 256, 0, st>>>(in, dpre, dw, d->N, d->C_in, d->H_in, d->W_in, tilesX,
+                                                                        tilesY)));
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}

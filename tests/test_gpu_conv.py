@@ -32,6 +32,8 @@ CASES = [
     ("c3x3_concat3", [64, 64, 1], 64, 3, 1, 1, 0, False, 1, (2, 16, 26), None),
     ("c3x3_concat2_odd", [16, 1], 16, 3, 1, 1, 0, False, 1, (1, 32, 52), None),
     ("head_sigmoid_affine", [16], 1, 3, 1, 1, 0, False, 2, (2, 32, 52), None),
+    ("head2_sigmoid_ragged", [19], 2, 3, 1, 1, 0, False, 2, (2, 21, 70), None),
+    ("head4_relu", [8], 4, 3, 1, 1, 0, False, 1, (1, 9, 130), None),
     ("mask_head_sigmoid", [32], 2, 3, 1, 1, 0, False, 2, (2, 16, 26), None),
     ("pose_pred_1x1", [256], 12, 1, 1, 0, 0, False, 0, (2, 2, 7), None),
     ("deep_splitk", [512], 512, 3, 1, 1, 0, False, 1, (2, 4, 13), None),
