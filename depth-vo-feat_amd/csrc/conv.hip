@@ -832,6 +832,37 @@ int dvf_conv2d_fwd(const dvf_conv_desc *d, const float *const *in_segs, const in
     return run_classes(a, cls, ncls, covers, dvf_stream(stream));
 }
 
+}  // extern "C"
+
+namespace {
+// dgrad of one input segment with the unpacked weights: the head kernel for narrow segments, else conv_gather_kernel
+int dgrad_segment_unpacked(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int off, int segc,
+                           hipStream_t st) {
+    if (dvf_head_seg_dgrad_applicable(d, segc)) return dvf_head_seg_dgrad(d, dpre, w, din, off, segc, st);
+    GatherArgs a{};
+    a.in[0] = dpre; a.segC[0] = d->C_out; a.nseg = 1;
+    a.w = w; a.KK = d->KH * d->KW; a.m_base = off; a.M = segc; a.bias = nullptr; a.out = din;
+    a.Mtot = d->C_in; a.Rtot = d->C_out;
+    a.N = d->N; a.IH = d->H_out; a.IW = d->W_out; a.OH = d->H_in; a.OW = d->W_in;
+    a.act = DVF_ACT_NONE;
+    ClassSpec cls[4];
+    if (!d->transposed) {
+        // din[ci][Y][X] = sum_co sum_ab W[co][ci][a][b] * dpre[co][o][..],  Y = o*s - p + a
+        a.w_mode = 1;
+        bool covers;
+        const int ncls = scatter_classes(d->stride, d->pad, d->KH, d->KW, d->H_in, d->W_in, cls, &covers);
+        return run_classes(a, cls, ncls, covers, st);
+    }
+    // din[ci][i][j] = sum_co sum_ab W[ci][co][a][b] * dpre[co][i*s - p + a][j*s - p + b]
+    a.w_mode = 0;
+    cls[0] = ClassSpec{1, 0, 0, d->stride, -d->pad, -d->pad, d->KH, d->KW, d->H_in, d->W_in, {0}};
+    for (int t = 0; t < a.KK; ++t) cls[0].tapmap[t] = t;
+    return run_classes(a, cls, 1, true, st);
+}
+}  // namespace
+
+extern "C" {
+
 int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *const *din_segs,
                      const int *seg_channels, int nseg, void *stream) {
     int rc = check_desc(d);
@@ -844,26 +875,7 @@ int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, 
     for (int s = 0; s < nseg; ++s) {
         const int segc = seg_channels[s];
         if (din_segs[s]) {
-            GatherArgs a{};
-            a.in[0] = dpre; a.segC[0] = d->C_out; a.nseg = 1;
-            a.w = w; a.KK = d->KH * d->KW; a.m_base = off; a.M = segc; a.bias = nullptr; a.out = din_segs[s];
-            a.Mtot = d->C_in; a.Rtot = d->C_out;
-            a.N = d->N; a.IH = d->H_out; a.IW = d->W_out; a.OH = d->H_in; a.OW = d->W_in;
-            a.act = DVF_ACT_NONE;
-            ClassSpec cls[4];
-            if (!d->transposed) {
-                // din[ci][Y][X] = sum_co sum_ab W[co][ci][a][b] * dpre[co][o][..],  Y = o*s - p + a
-                a.w_mode = 1;
-                bool covers;
-                const int ncls = scatter_classes(d->stride, d->pad, d->KH, d->KW, d->H_in, d->W_in, cls, &covers);
-                rc = run_classes(a, cls, ncls, covers, dvf_stream(stream));
-            } else {
-                // din[ci][i][j] = sum_co sum_ab W[ci][co][a][b] * dpre[co][i*s - p + a][j*s - p + b]
-                a.w_mode = 0;
-                cls[0] = ClassSpec{1, 0, 0, d->stride, -d->pad, -d->pad, d->KH, d->KW, d->H_in, d->W_in, {0}};
-                for (int t = 0; t < a.KK; ++t) cls[0].tapmap[t] = t;
-                rc = run_classes(a, cls, 1, true, dvf_stream(stream));
-            }
+            rc = dgrad_segment_unpacked(d, dpre, w, din_segs[s], off, segc, dvf_stream(stream));
             if (rc) return rc;
         }
         off += segc;
@@ -980,6 +992,7 @@ int64_t pipe_sizes(const dvf_conv_desc *d, const int *seg_channels, int nseg, in
     if (rc) return rc;
     PipeOp op;
     int64_t total = 0, nf = 0, wf = 0, wmax = 0;
+    int nsup = 0;
     if (op_kind == 0) {
         rc = make_fwd_op(d, nullptr, seg_channels, nseg, nullptr, nullptr, op);
         if (rc) return rc;
@@ -992,11 +1005,15 @@ int64_t pipe_sizes(const dvf_conv_desc *d, const int *seg_channels, int nseg, in
         rc = make_dgrad_op(d, nullptr, nullptr, off, seg_channels[s], op);
         if (rc) return rc;
         rc = pipe_pack(op, nullptr, nullptr, &nf, &wf, nullptr);
-        if (rc) return rc;
-        total += nf;
-        wmax = wf > wmax ? wf : wmax;
+        if (rc && rc != DVF_ERR_UNSUPPORTED) return rc;
+        if (!rc) {                                           // (unsupported segments run unpacked: no packed share)
+            total += nf;
+            wmax = wf > wmax ? wf : wmax;
+            ++nsup;
+        }
         off += seg_channels[s];
     }
+    if (!nsup) return DVF_ERR_UNSUPPORTED;
     return want_ws ? wmax : total;
 }
 
@@ -1032,8 +1049,8 @@ int dvf_conv2d_pack(const dvf_conv_desc *d, const int *seg_channels, int nseg, i
         rc = make_dgrad_op(d, nullptr, nullptr, off, seg_channels[s], op);
         if (rc) return rc;
         rc = pipe_pack(op, w, packed, &nf, nullptr, dvf_stream(stream));
-        if (rc) return rc;
-        packed += nf;
+        if (rc && rc != DVF_ERR_UNSUPPORTED) return rc;
+        if (!rc) packed += nf;
         off += seg_channels[s];
     }
     return DVF_OK;
@@ -1054,8 +1071,9 @@ int dvf_conv2d_fwd_packed(const dvf_conv_desc *d, const float *const *in_segs, c
     return pipe_run(op, packed, ws, ws_floats, dvf_stream(stream));
 }
 
-int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const float *packed, float *const *din_segs,
-                            const int *seg_channels, int nseg, float *ws, int64_t ws_floats, void *stream) {
+int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const float *packed, const float *w,
+                            float *const *din_segs, const int *seg_channels, int nseg, float *ws, int64_t ws_floats,
+                            void *stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     rc = check_segs(d, seg_channels, nseg);
@@ -1067,13 +1085,21 @@ int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const flo
         rc = make_dgrad_op(d, dpre, din_segs[s], off, seg_channels[s], op);
         if (rc) return rc;
         int64_t nf = 0;
-        if (din_segs[s]) {
-            rc = pipe_run(op, packed, ws, ws_floats, dvf_stream(stream));
-            if (rc) return rc;
+        rc = pipe_pack(op, nullptr, nullptr, &nf, nullptr, nullptr);      // plan only: is this segment packed?
+        if (rc && rc != DVF_ERR_UNSUPPORTED) return rc;
+        if (rc == DVF_ERR_UNSUPPORTED) {                                  // narrow segment: unpacked kernels
+            if (din_segs[s]) {
+                if (!w) return DVF_ERR_INVALID_ARG;
+                rc = dgrad_segment_unpacked(d, dpre, w, din_segs[s], off, seg_channels[s], dvf_stream(stream));
+                if (rc) return rc;
+            }
+        } else {
+            if (din_segs[s]) {
+                rc = pipe_run(op, packed, ws, ws_floats, dvf_stream(stream));
+                if (rc) return rc;
+            }
+            packed += nf;
         }
-        rc = pipe_pack(op, nullptr, nullptr, &nf, nullptr, nullptr);
-        if (rc) return rc;
-        packed += nf;
         off += seg_channels[s];
     }
     return DVF_OK;
@@ -1116,8 +1142,8 @@ int dvf_conv2d_pack_jobs(const dvf_conv_desc *d, const int *seg_channels, int ns
         rc = make_dgrad_op(d, nullptr, nullptr, off, seg_channels[s], op);
         if (rc) return rc;
         rc = emit(op, packed);
-        if (rc) return rc;
-        packed += nf;
+        if (rc && rc != DVF_ERR_UNSUPPORTED) return rc;
+        if (!rc) packed += nf;
         off += seg_channels[s];
     }
     return njobs;

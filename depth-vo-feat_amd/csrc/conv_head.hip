@@ -28,10 +28,13 @@ __device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__
 }
 
 // out[n][mo][y][x] = act(b[mo] + sum_c sum_taps w[mo][c][tap] * in[n][c][y+ta-1][x+tb-1])
+// Weight addressing is general: w[m * ws_m + c * ws_c + tap'] with tap' = flip ? 8 - tap : tap, so the same kernel also
+// computes the dgrad of a narrow input segment (m = segment channel, c = output channel of the convolution, taps flipped).
 template <int MO>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                        const float *__restrict__ bias, float *__restrict__ out, int C, int H,
-                                                       int W, int tilesX, int act, float alpha, float beta) {
+                                                       int W, int tilesX, int act, float alpha, float beta, int ws_m, int ws_c,
+                                                       int flip) {
     __shared__ float tile[HCK * HP_H * HP_W];
     const int n = blockIdx.y, tY = blockIdx.x / tilesX, tX = blockIdx.x - tY * tilesX;
     const int y0 = tY * HT_H, x0 = tX * HT_W;
@@ -54,9 +57,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
                 for (int b = 0; b < 3; ++b) v[a * 3 + b] = t[a * HP_W + b];
 #pragma unroll
             for (int m = 0; m < MO; ++m) {
-                const float *wm = w + ((int64_t)m * C + c0 + ch) * 9;        // uniform address: scalar loads
+                const float *wm = w + (int64_t)m * ws_m + (int64_t)(c0 + ch) * ws_c;        // uniform address: scalar loads
+                if (flip) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) acc[m] = fmaf(wm[k], v[k], acc[m]);
+                    for (int k = 0; k < 9; ++k) acc[m] = fmaf(wm[8 - k], v[k], acc[m]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) acc[m] = fmaf(wm[k], v[k], acc[m]);
+                }
             }
         }
     }
@@ -177,7 +185,26 @@ int dvf_head_fwd(const dvf_conv_desc *d, const float *in, const float *w, const 
     const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, HT_H);
     const dim3 grid(tilesX * tilesY, d->N);
     HEAD_DISPATCH(d->C_out, (head_fwd_kernel<MO><<<grid, 256, 0, st>>>(in, w, bias, out, d->C_in, d->H_in, d->W_in, tilesX,
-                                                                      d->act, d->alpha, d->beta)));
+                                                                      d->act, d->alpha, d->beta, d->C_in * 9, 9, 0)));
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
+// dgrad of ONE narrow input segment (segc <= 4 channels starting at seg_off) of a 3x3 stride-1 pad-1 Conv2d:
+//   din[n][ci][y][x] = sum_co sum_taps w[co][seg_off+ci][ta][tb] * dpre[n][co][y-ta+1][x-tb+1]
+// = the head forward over dpre with transposed, tap-flipped weights.
+bool dvf_head_seg_dgrad_applicable(const dvf_conv_desc *d, int segc) {
+    return !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && segc >= 1 && segc <= 4 &&
+           d->H_out == d->H_in && d->W_out == d->W_in && d->C_out >= 4 && getenv("DVF_NO_HEAD") == nullptr;
+}
+
+int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int seg_off, int segc,
+                       hipStream_t st) {
+    const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, HT_H);
+    const dim3 grid(tilesX * tilesY, d->N);
+    const float *wseg = w + (int64_t)seg_off * 9;
+    HEAD_DISPATCH(segc, (head_fwd_kernel<MO><<<grid, 256, 0, st>>>(dpre, wseg, nullptr, din, d->C_out, d->H_in, d->W_in, tilesX,
+                                                                  DVF_ACT_NONE, 1.f, 0.f, 9, d->C_in * 9, 1)));
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }

@@ -189,7 +189,7 @@ class ConvFn(torch.autograd.Function):
             packed, ws = _packed_weights(weight, ctx.holder, desc, segc, 1)
             with L.timed("conv_dgrad", 2 * ctx.macs * frac, tag=ctx.tag):
                 if packed is not None:
-                    L.check(lib.dvf_conv2d_dgrad_packed(ctypes.byref(desc), L.dev(dpre), L.dev(packed), L.ptr_array(gins),
+                    L.check(lib.dvf_conv2d_dgrad_packed(ctypes.byref(desc), L.dev(dpre), L.dev(packed), L.dev(weight), L.ptr_array(gins),
                                                         L.int_array(segc), len(segc), L.dev(ws),
                                                         ws.numel() if ws is not None else 0, L.stream()),
                             "dvf_conv2d_dgrad_packed")

@@ -155,8 +155,11 @@ int dvf_conv2d_pack(const dvf_conv_desc *d, const int *seg_channels, int nseg, i
                     void *stream);
 int dvf_conv2d_fwd_packed(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
                           const float *packed, const float *bias, float *out, float *ws, int64_t ws_floats, void *stream);
-int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const float *packed, float *const *din_segs,
-                            const int *seg_channels, int nseg, float *ws, int64_t ws_floats, void *stream);
+/* (dgrad: input segments the pipelined kernel does not take -- at most 32 channels -- have no share in the packed copy
+ * and are computed from the unpacked weights w, which may be NULL only if every segment is packed) */
+int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const float *packed, const float *w,
+                            float *const *din_segs, const int *seg_channels, int nseg, float *ws, int64_t ws_floats,
+                            void *stream);
 /* Optional split-K workspace of the packed entries: with ws (>= dvf_conv2d_ws_floats(...) floats, contents
  * irrelevant) small grids split the reduction over blocks that store plain partial tiles which one pass reduces
  * (+bias, activation); with ws == NULL they accumulate with float atomics into a zeroed output instead. */
