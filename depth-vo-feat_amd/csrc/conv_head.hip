@@ -30,48 +30,74 @@ __device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__
 // out[n][mo][y][x] = act(b[mo] + sum_c sum_taps w[mo][c][tap] * in[n][c][y+ta-1][x+tb-1])
 // Weight addressing is general: w[m * ws_m + c * ws_c + tap'] with tap' = flip ? 8 - tap : tap, so the same kernel also
 // computes the dgrad of a narrow input segment (m = segment channel, c = output channel of the convolution, taps flipped).
+// Tile 64 x 8 pixels, two rows per thread; the per-thread staging offsets are channel-invariant.
+constexpr int FT_H = 8, FP_H = FT_H + 2, FP_N = FP_H * HP_W, F_LD = (FP_N + 255) / 256;
 template <int MO>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                        const float *__restrict__ bias, float *__restrict__ out, int C, int H,
                                                        int W, int tilesX, int act, float alpha, float beta, int ws_m, int ws_c,
                                                        int flip) {
-    __shared__ float tile[HCK * HP_H * HP_W];
+    __shared__ float tile[HCK * FP_N];
     const int n = blockIdx.y, tY = blockIdx.x / tilesX, tX = blockIdx.x - tY * tilesX;
-    const int y0 = tY * HT_H, x0 = tX * HT_W;
-    const int lx = threadIdx.x & (HT_W - 1), ly = threadIdx.x >> 6;
+    const int y0 = tY * FT_H, x0 = tX * HT_W;
+    const int lx = threadIdx.x & (HT_W - 1), ly = (threadIdx.x >> 6) * 2;      // rows ly, ly+1
     const int64_t plane = (int64_t)H * W;
-    float acc[MO];
+    int soff[F_LD];                          // source offset inside a plane (or -1: zero / not mine)
 #pragma unroll
-    for (int m = 0; m < MO; ++m) acc[m] = bias ? bias[m] : 0.f;
+    for (int i = 0; i < F_LD; ++i) {
+        const int e = threadIdx.x + 256 * i, py = e / HP_W, px = e - py * HP_W;
+        const int y = y0 + py - 1, x = x0 + px - 1;
+        soff[i] = (e < FP_N && y >= 0 && y < H && x >= 0 && x < W) ? y * W + x : -1;
+    }
+    float acc[2][MO];
+#pragma unroll
+    for (int m = 0; m < MO; ++m) acc[0][m] = acc[1][m] = bias ? bias[m] : 0.f;
     for (int c0 = 0; c0 < C; c0 += HCK) {
         const int nch = min(HCK, C - c0);
+        const float *src = in + ((int64_t)n * C + c0) * plane;
+        // all loads of the chunk first (independent, in flight together), then the LDS stores
+        float stg[HCK][F_LD];
+#pragma unroll
+        for (int ch = 0; ch < HCK; ++ch)
+#pragma unroll
+            for (int i = 0; i < F_LD; ++i) stg[ch][i] = (ch < nch && soff[i] >= 0) ? src[ch * plane + soff[i]] : 0.f;
         __syncthreads();
-        stage_tile(tile, in + ((int64_t)n * C + c0) * plane, plane, nch, H, W, y0, x0);
+#pragma unroll
+        for (int ch = 0; ch < HCK; ++ch)
+#pragma unroll
+            for (int i = 0; i < F_LD; ++i) {
+                const int e = threadIdx.x + 256 * i;
+                if (e < FP_N) tile[ch * FP_N + e] = stg[ch][i];
+            }
         __syncthreads();
         for (int ch = 0; ch < nch; ++ch) {
-            const float *t = tile + ch * (HP_H * HP_W) + ly * HP_W + lx;
-            float v[9];
+            const float *t = tile + ch * FP_N + ly * HP_W + lx;
+            float v[4][3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) v[a * 3 + b] = t[a * HP_W + b];
+                for (int b = 0; b < 3; ++b) v[a][b] = t[a * HP_W + b];
 #pragma unroll
             for (int m = 0; m < MO; ++m) {
                 const float *wm = w + (int64_t)m * ws_m + (int64_t)(c0 + ch) * ws_c;        // uniform address: scalar loads
-                if (flip) {
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) acc[m] = fmaf(wm[8 - k], v[k], acc[m]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) acc[m] = fmaf(wm[k], v[k], acc[m]);
+                for (int k = 0; k < 9; ++k) {
+                    const float wk = flip ? wm[8 - k] : wm[k];
+                    acc[0][m] = fmaf(wk, v[k / 3][k % 3], acc[0][m]);
+                    acc[1][m] = fmaf(wk, v[k / 3 + 1][k % 3], acc[1][m]);
                 }
             }
         }
     }
-    const int y = y0 + ly, x = x0 + lx;
-    if (y < H && x < W) {
+    const int x = x0 + lx;
 #pragma unroll
-        for (int m = 0; m < MO; ++m) out[((int64_t)n * MO + m) * plane + (int64_t)y * W + x] = head_act(acc[m], act, alpha, beta);
+    for (int r = 0; r < 2; ++r) {
+        const int y = y0 + ly + r;
+        if (y < H && x < W) {
+#pragma unroll
+            for (int m = 0; m < MO; ++m)
+                out[((int64_t)n * MO + m) * plane + (int64_t)y * W + x] = head_act(acc[r][m], act, alpha, beta);
+        }
     }
 }
 
@@ -182,7 +208,7 @@ bool dvf_head_applicable(const dvf_conv_desc *d, int nseg) {
     }
 
 int dvf_head_fwd(const dvf_conv_desc *d, const float *in, const float *w, const float *bias, float *out, hipStream_t st) {
-    const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, HT_H);
+    const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, FT_H);
     const dim3 grid(tilesX * tilesY, d->N);
     HEAD_DISPATCH(d->C_out, (head_fwd_kernel<MO><<<grid, 256, 0, st>>>(in, w, bias, out, d->C_in, d->H_in, d->W_in, tilesX,
                                                                       d->act, d->alpha, d->beta, d->C_in * 9, 9, 0)));
@@ -200,7 +226,7 @@ bool dvf_head_seg_dgrad_applicable(const dvf_conv_desc *d, int segc) {
 
 int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int seg_off, int segc,
                        hipStream_t st) {
-    const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, HT_H);
+    const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, FT_H);
     const dim3 grid(tilesX * tilesY, d->N);
     const float *wseg = w + (int64_t)seg_off * 9;
     HEAD_DISPATCH(segc, (head_fwd_kernel<MO><<<grid, 256, 0, st>>>(dpre, wseg, nullptr, din, d->C_out, d->H_in, d->W_in, tilesX,
