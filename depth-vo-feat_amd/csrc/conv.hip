@@ -937,7 +937,8 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
         a.CK = CK;
         const int mtiles = cdiv(a.M, 32 * MT), cchunks = cdiv(a.Cq, CK);
         const int ntiles = a.N * a.tilesX * a.tilesY;
-        int psplit = 1024 / (mtiles * cchunks);
+        static const int wg_target = getenv("DVF_WG_BLOCKS") ? atoi(getenv("DVF_WG_BLOCKS")) : 768;    // tuning knob (swept on cfg 2: 512..2048)
+        int psplit = wg_target / (mtiles * cchunks);
         if (psplit < 1) psplit = 1;
         if (psplit > ntiles) psplit = ntiles;
         if (psplit > 65535 || cchunks > 65535) return DVF_ERR_UNSUPPORTED;
