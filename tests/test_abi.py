@@ -45,3 +45,41 @@ def test_product_refuses_cpu_tensors():
     d = torch.rand(1, 1, 8, 8)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         loss_functions.smooth_loss(d)
+
+
+def _desc(n, cin, h, w, cout, k=3, stride=1, pad=1, transposed=0):
+    oh = (h - 1) * stride - 2 * pad + k + (1 if transposed and stride == 2 and k == 3 else 0) if transposed else (h + 2 * pad - k) // stride + 1
+    ow = (w - 1) * stride - 2 * pad + k + (1 if transposed and stride == 2 and k == 3 else 0) if transposed else (w + 2 * pad - k) // stride + 1
+    return L.ConvDesc(n, cin, h, w, cout, oh, ow, k, k, stride, pad, transposed, L.ACT_RELU, 1.0, 0.0)
+
+
+def test_packed_weight_planner_is_host_only_and_consistent():
+    """The planning half of the packed-weight protocol (sizes, job records) runs on the host: check it here."""
+    import ctypes
+    lib = L.lib()
+    d = _desc(4, 128, 32, 104, 128)
+    segs = L.int_array([128])
+    nf = lib.dvf_conv2d_packed_floats(ctypes.byref(d), segs, 1, 0)
+    assert nf >= 128 * 128 * 9 and nf % 256 == 0                 # at least the weights, whole 1 KiB pieces
+    assert lib.dvf_conv2d_packed_floats(ctypes.byref(d), segs, 1, 1) >= 128 * 128 * 9
+    assert lib.dvf_conv2d_ws_floats(ctypes.byref(d), segs, 1, 0) >= 0
+    assert lib.dvf_conv2d_packed_floats(ctypes.byref(d), segs, 1, 7) == -1          # bad op_kind
+    # at most 32 output channels: stays on the unpacked kernels
+    small = _desc(4, 65, 128, 416, 32)
+    assert lib.dvf_conv2d_packed_floats(ctypes.byref(small), L.int_array([32, 32, 1]), 3, 0) == L.ERR_UNSUPPORTED
+    # virtual concat with a 1-channel segment: the wide segments are packed for dgrad, the narrow one is not
+    cat = _desc(4, 257, 32, 104, 128)
+    segs3 = L.int_array([128, 128, 1])
+    n_dgrad = lib.dvf_conv2d_packed_floats(ctypes.byref(cat), segs3, 3, 1)
+    assert n_dgrad >= 2 * 128 * 128 * 9
+    # job records: one per packed op instance, block counts positive (pointers are recorded, not dereferenced)
+    buf = (ctypes.c_char * (L.PACK_JOB_BYTES * 3))()
+    blocks = (ctypes.c_int * 3)()
+    lds = ctypes.c_int(4)
+    fake = ctypes.c_void_p(0x1000)
+    n = lib.dvf_conv2d_pack_jobs(ctypes.byref(cat), segs3, 3, 1, fake, fake, ctypes.cast(buf, ctypes.c_void_p), 3, blocks,
+                                 ctypes.byref(lds))
+    assert n == 2 and blocks[0] > 0 and blocks[1] > 0 and 4 < lds.value <= 64 * 1024
+    # strided transposed convolution (4 output-parity classes share one packed buffer)
+    up = _desc(4, 256, 16, 52, 128, 3, 2, 1, 1)
+    assert lib.dvf_conv2d_packed_floats(ctypes.byref(up), L.int_array([256]), 1, 0) >= 256 * 128 * 9
