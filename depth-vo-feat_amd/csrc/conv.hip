@@ -324,7 +324,7 @@ struct WgradArgs {
 
 constexpr int WG_BW = 32;
 
-template <int MT, int NTW>
+template <int MT, int NTW, bool PF>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int COTP = 32 * MT + 1;              // padded row of the transposed P tile (compile-time: immediate offsets)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -369,11 +369,87 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         qcol_dst[ps] = (cc < a.PWq) ? ((a.S == 2) ? ((cc & 1) * a.PWH + (cc >> 1)) : cc) : -1;
     }
     const int ntiles = a.N * a.tilesX * a.tilesY;
-    for (int tile = blockIdx.z; tile < ntiles; tile += a.PSPLIT) {
-        const int n = tile / (a.tilesX * a.tilesY), rem = tile - n * (a.tilesX * a.tilesY);
+    // Staging is split into ISSUE (global loads into registers) and STORE (registers -> LDS).  With PF the loads of
+    // tile t+1 are issued right before the MFMA phase of tile t and stored after it, so their latency hides behind the
+    // MFMAs (the register budget allows it when a wave stages at most WG_QMAX patch rows in one pass).
+    constexpr int WG_QMAX = 24, WG_PMAX = 16 * MT;
+    float qreg[WG_QMAX], preg[WG_PMAX];
+    const int npairs = a.BH >> 1, ptotal = 32 * MT * npairs;
+    auto tile_origin = [&](int tile, int &n, int &gy0, int &gx0) {
+        n = tile / (a.tilesX * a.tilesY);
+        const int rem = tile - n * (a.tilesX * a.tilesY);
         const int tY = rem / a.tilesX, tX = rem - tY * a.tilesX;
-        const int gy0 = tY * a.BH, gx0 = tX * WG_BW;
+        gy0 = tY * a.BH;
+        gx0 = tX * WG_BW;
+    };
+    auto issue_tile = [&](int tile) {
+        int n, gy0, gx0;
+        tile_origin(tile, n, gy0, gx0);
+        {   // Q patch rows wave, wave+4, ...: one 64-lane load per row (single pass: PWq <= 64)
+            const int qy0 = gy0 * a.S - a.pad, qx0 = gx0 * a.S - a.pad;
+            const unsigned cb = (unsigned)((n * a.QCtot + a.q_base + c0) * a.QH * a.QW) << 2;
+            const int ix = qx0 + lane;
+            const unsigned qoff = (lane < a.PWq && ix >= 0 && ix < a.QW) ? ((unsigned)ix << 2) : OOB;
+            int ci = 0, r = wave;
+            while (r >= a.PHq) { r -= a.PHq; ++ci; }
+#pragma unroll
+            for (int k = 0; k < WG_QMAX; ++k) {
+                if (ci < a.CK) {
+                    const int iy = qy0 + r;
+                    const bool rowok = (ci < nch) & (iy >= 0) & (iy < a.QH);
+                    const unsigned soff = cb + ((unsigned)((ci * a.QH + iy) * a.QW) << 2);
+                    qreg[k] = bload(rs_q, rowok ? qoff : OOB, rowok ? soff : 0u);
+                    r += 4;
+                    while (r >= a.PHq) { r -= a.PHq; ++ci; }
+                }
+            }
+        }
+        {   // P tile: item idx = (channel m, row pair rp); half-wave = one row of 32 pixels
+            const int px = lane & 31, prow = lane >> 5;
+            const bool colok = gx0 + px < a.GW;
+            const unsigned pb = (unsigned)((n * a.PCtot + a.m_base + m0) * a.GH * a.GW) << 2;
+#pragma unroll
+            for (int k = 0; k < WG_PMAX; ++k) {
+                const int idx = wave + 4 * k;
+                const int m = idx >> a.lnp, rp = idx - (m << a.lnp);
+                const int gy = gy0 + rp * 2 + prow;
+                const bool mok = (idx < ptotal) & (m0 + m < a.M);
+                const unsigned voff = (colok && gy < a.GH) ? ((unsigned)(gy * a.GW + gx0 + px) << 2) : OOB;
+                preg[k] = bload(rs_p, mok ? voff : OOB, mok ? pb + ((unsigned)(m * a.GH * a.GW) << 2) : 0u);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+        {
+            int ci = 0, r = wave;
+            while (r >= a.PHq) { r -= a.PHq; ++ci; }
+#pragma unroll
+            for (int k = 0; k < WG_QMAX; ++k) {
+                if (ci < a.CK) {
+                    if (qcol_dst[0] >= 0) qp[ci * a.PS + r * a.RS + qcol_dst[0]] = qreg[k];
+                    r += 4;
+                    while (r >= a.PHq) { r -= a.PHq; ++ci; }
+                }
+            }
+        }
+        {
+            const int px = lane & 31, prow = lane >> 5;
+#pragma unroll
+            for (int k = 0; k < WG_PMAX; ++k) {
+                const int idx = wave + 4 * k;
+                const int m = idx >> a.lnp, rp = idx - (m << a.lnp);
+                if (idx < ptotal) pl[((rp * 2 + prow) * WG_BW + px) * COTP + m] = preg[k];
+            }
+        }
+    };
+    if (PF && blockIdx.z < ntiles) issue_tile(blockIdx.z);
+    for (int tile = blockIdx.z; tile < ntiles; tile += a.PSPLIT) {
+        int n, gy0, gx0;
+        tile_origin(tile, n, gy0, gx0);
         __syncthreads();
+        if (PF) {
+            store_tile();
+        } else {
         // ---- stage Q patch: scalar incremental row bookkeeping, lane-invariant column part, buffer loads (zero fill)
         {
             const int qy0 = gy0 * a.S - a.pad, qx0 = gx0 * a.S - a.pad;
@@ -438,7 +514,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 }
             }
         }
+        }
         __syncthreads();
+        if (PF && tile + a.PSPLIT < ntiles) issue_tile(tile + a.PSPLIT);     // in flight during the MFMA phase
         // ---- MFMA over pixel pairs: groups of 4 steps, the next group's fragments are fetched first
         {
             float af[2][4][MT], bf[2][4][NTW];
@@ -949,10 +1027,20 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
             (int64_t)a.N * a.QCtot * a.QH * a.QW * 4 >= ((int64_t)1 << 31) - 16)
             return DVF_ERR_UNSUPPORTED;             // 32-bit byte offsets inside the kernel
         const dim3 grid(mtiles, cchunks, psplit);
-        if (MT == 2 && NTW == 2) conv_wgrad_kernel<2, 2><<<grid, 256, lds, st>>>(a);
-        else if (MT == 2) conv_wgrad_kernel<2, 1><<<grid, 256, lds, st>>>(a);
-        else if (NTW == 2) conv_wgrad_kernel<1, 2><<<grid, 256, lds, st>>>(a);
-        else conv_wgrad_kernel<1, 1><<<grid, 256, lds, st>>>(a);
+        // register prefetch of the next tile when a wave's share of the Q patch fits the register budget (one pass)
+        static const bool no_pf = getenv("DVF_WG_NOPF") != nullptr;
+        const bool pf = !no_pf && a.PWq <= 64 && cdiv(CK * a.PHq, 4) <= 24 && 8 * MT * (a.BH >> 1) <= 16 * MT;
+        if (pf) {
+            if (MT == 2 && NTW == 2) conv_wgrad_kernel<2, 2, true><<<grid, 256, lds, st>>>(a);
+            else if (MT == 2) conv_wgrad_kernel<2, 1, true><<<grid, 256, lds, st>>>(a);
+            else if (NTW == 2) conv_wgrad_kernel<1, 2, true><<<grid, 256, lds, st>>>(a);
+            else conv_wgrad_kernel<1, 1, true><<<grid, 256, lds, st>>>(a);
+        } else {
+            if (MT == 2 && NTW == 2) conv_wgrad_kernel<2, 2, false><<<grid, 256, lds, st>>>(a);
+            else if (MT == 2) conv_wgrad_kernel<2, 1, false><<<grid, 256, lds, st>>>(a);
+            else if (NTW == 2) conv_wgrad_kernel<1, 2, false><<<grid, 256, lds, st>>>(a);
+            else conv_wgrad_kernel<1, 1, false><<<grid, 256, lds, st>>>(a);
+        }
         DVF_LAUNCH_CHECK();
         off += segc;
     }
