@@ -168,6 +168,8 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     // Layers with at most 32 output channels have little MFMA work per staged input byte: their patch DMA (4-byte
     // lanes) saturates the texture-address path before the matrix pipe, and the register-staged conv_gather_kernel is
     // faster (tools/conv_bench.py, round 1).  They stay on that kernel until the patch is staged in 16-byte lanes.
+    // (tried in round 1: staging the patch in 16-byte lanes -- 4x SLOWER than 4-byte lanes for these short row-strided
+    // runs, loads-only 82 us vs 30 us on the 3x3 128->128 @32x104 layer -- so that is not the way to bring them over)
     if (a.M <= 32 && !ov.on) return DVF_ERR_UNSUPPORTED;
     if (ov.on && ov.KS < 0) return DVF_ERR_UNSUPPORTED;      // (tuning: force the gather kernel)
     int maxc = 0;

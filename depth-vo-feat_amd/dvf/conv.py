@@ -148,12 +148,14 @@ class ConvFn(torch.autograd.Function):
         ctx.tag = f"{'T' if transposed else 'C'}{k}x{k}s{stride} {cin}->{cout} in{H}x{W} out{oh}x{ow} N{N}"
         packed, ws = _packed_weights(weight, ctx.holder, desc, segc, 0)
         with L.timed("conv_fwd", 2 * ctx.macs, tag=ctx.tag):
+            rc = L.ERR_UNSUPPORTED
             if packed is not None:
-                L.check(L.lib().dvf_conv2d_fwd_packed(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc),
-                                                      len(segc), L.dev(packed), L.dev(bias, "bias"), L.dev(out),
-                                                      L.dev(ws), ws.numel() if ws is not None else 0, L.stream()),
-                        "dvf_conv2d_fwd_packed")
-            else:
+                rc = L.lib().dvf_conv2d_fwd_packed(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc),
+                                                   len(segc), L.dev(packed), L.dev(bias, "bias"), L.dev(out),
+                                                   L.dev(ws), ws.numel() if ws is not None else 0, L.stream())
+                if rc != L.ERR_UNSUPPORTED:             # (unsupported at run time: an operand is not 16-byte aligned)
+                    L.check(rc, "dvf_conv2d_fwd_packed")
+            if rc == L.ERR_UNSUPPORTED:
                 L.check(L.lib().dvf_conv2d_fwd(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc),
                                                len(segc), L.dev(weight, "weight"), L.dev(bias, "bias"), L.dev(out),
                                                L.stream()), "dvf_conv2d_fwd")
@@ -188,12 +190,14 @@ class ConvFn(torch.autograd.Function):
             frac = sum(c for c, need in zip(segc, need_in) if need) / float(sum(segc))
             packed, ws = _packed_weights(weight, ctx.holder, desc, segc, 1)
             with L.timed("conv_dgrad", 2 * ctx.macs * frac, tag=ctx.tag):
+                rc = L.ERR_UNSUPPORTED
                 if packed is not None:
-                    L.check(lib.dvf_conv2d_dgrad_packed(ctypes.byref(desc), L.dev(dpre), L.dev(packed), L.dev(weight), L.ptr_array(gins),
-                                                        L.int_array(segc), len(segc), L.dev(ws),
-                                                        ws.numel() if ws is not None else 0, L.stream()),
-                            "dvf_conv2d_dgrad_packed")
-                else:
+                    rc = lib.dvf_conv2d_dgrad_packed(ctypes.byref(desc), L.dev(dpre), L.dev(packed), L.dev(weight),
+                                                     L.ptr_array(gins), L.int_array(segc), len(segc), L.dev(ws),
+                                                     ws.numel() if ws is not None else 0, L.stream())
+                    if rc != L.ERR_UNSUPPORTED:
+                        L.check(rc, "dvf_conv2d_dgrad_packed")
+                if rc == L.ERR_UNSUPPORTED:
                     L.check(lib.dvf_conv2d_dgrad(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins),
                                                  L.int_array(segc), len(segc), L.stream()), "dvf_conv2d_dgrad")
         dw = None
