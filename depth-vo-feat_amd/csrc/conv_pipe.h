@@ -275,8 +275,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs 
         const float *wl = smem + st * stage_floats;
         const float *patch = wl + a.SLmax;
         const float *ap = wl + (wm * MT) * 64 * VW + lane * VW;
-        avec af[2][TBU][MT];
-        float bf[2][TBU][NT][VW];
+        avec af[2][MT];                                    // A fragments: ping-pong by tap (one tap ahead)
+        float bf[2][TBU][NT][VW];                          // B fragments: ping-pong by unit (one unit ahead)
         int lta = 0, lcpg = 0, lk = 0;                     // load iterator (scalar): next unit to fetch
         auto load_b = [&](auto bufc) {
             constexpr int buf = decltype(bufc)::value;
@@ -296,11 +296,12 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs 
                     }
                 }
         };
-        auto load_a = [&](auto bufc, auto uc) {
-            constexpr int buf = decltype(bufc)::value, u = decltype(uc)::value;
-            const float *aptr = ap + lk * UNITF;
+        // A fragments of tap u of unit `unit` (scalar) into ping-pong buffer tp
+        auto load_a = [&](auto tpc, int unit, auto uc) {
+            constexpr int tp = decltype(tpc)::value, u = decltype(uc)::value;
+            const float *aptr = ap + unit * UNITF;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) af[buf][u][m] = *reinterpret_cast<const avec *>(aptr + (u * MTW + m) * 64 * VW);
+            for (int m = 0; m < MT; ++m) af[tp][m] = *reinterpret_cast<const avec *>(aptr + (u * MTW + m) * 64 * VW);
         };
         auto advance = [&]() {
             ++lk;
@@ -308,14 +309,14 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs 
             lcpg = wrap ? 0 : lcpg + 1;
             lta += wrap ? 1 : 0;
         };
-        auto mma_tap = [&](auto bufc, auto uc) {
-            constexpr int buf = decltype(bufc)::value, u = decltype(uc)::value;
+        auto mma_tap = [&](auto bufc, auto tpc, auto uc) {
+            constexpr int buf = decltype(bufc)::value, tp = decltype(tpc)::value, u = decltype(uc)::value;
 #pragma unroll
             for (int j = 0; j < VW; ++j)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     float av;
-                    if constexpr (VW == 1) av = af[buf][u][m]; else av = af[buf][u][m][j];
+                    if constexpr (VW == 1) av = af[tp][m]; else av = af[tp][m][j];
 #pragma unroll
                     for (int i = 0; i < NT; ++i)
                         acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[buf][u][i][j], acc[m][i], 0, 0, 0);
@@ -323,37 +324,36 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs 
         };
         using B0 = std::integral_constant<int, 0>;
         using B1 = std::integral_constant<int, 1>;
-        // tap by tap: this unit's MFMAs of tap u, then the next unit's loads (all B rows behind tap 0, A of tap u behind
-        // tap u).  The scheduling barriers keep hipcc from sinking the loads next to their uses.
-        auto step = [&](auto bufc, auto nbufc, auto uc) {
-            mma_tap(bufc, uc);
-            if constexpr (decltype(uc)::value == 0) load_b(nbufc);
-            load_a(nbufc, uc);
+        // tap by tap: this unit's MFMAs of tap u, then the loads behind them: the A fragments of the NEXT tap (this unit's
+        // tap u+1, or the next unit's tap 0) and, behind tap 0, all B rows of the next unit.  lk = index of the next unit.
+        // Keeping A only one tap ahead (not a whole unit) saves 32-48 VGPRs: 135 instead of 183 for the 3x3 / 8-channel
+        // variant, i.e. three waves per SIMD = two blocks per CU.  The scheduling barriers keep hipcc from sinking the
+        // loads next to their uses.
+        auto step = [&](auto bufc, auto nbufc, auto pbc, auto uc) {
+            constexpr int u = decltype(uc)::value, tp = (decltype(pbc)::value + u) & 1;
+            mma_tap(bufc, std::integral_constant<int, tp>{}, uc);
+            if constexpr (u == 0) load_b(nbufc);
+            if constexpr (u + 1 < TBU) load_a(std::integral_constant<int, tp ^ 1>{}, lk - 1, std::integral_constant<int, u + 1>{});
+            else load_a(std::integral_constant<int, tp ^ 1>{}, lk, std::integral_constant<int, 0>{});
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto unit = [&](auto bufc, auto nbufc) {
-            step(bufc, nbufc, std::integral_constant<int, 0>{});
-            if constexpr (TBU > 1) step(bufc, nbufc, std::integral_constant<int, 1>{});
-            if constexpr (TBU > 2) step(bufc, nbufc, std::integral_constant<int, 2>{});
-            if constexpr (TBU > 3) step(bufc, nbufc, std::integral_constant<int, 3>{});
-            if constexpr (TBU > 4) step(bufc, nbufc, std::integral_constant<int, 4>{});
-            if constexpr (TBU > 5) step(bufc, nbufc, std::integral_constant<int, 5>{});
-            if constexpr (TBU > 6) step(bufc, nbufc, std::integral_constant<int, 6>{});
+        auto unit = [&](auto bufc, auto nbufc, auto pbc) {
+            step(bufc, nbufc, pbc, std::integral_constant<int, 0>{});
+            if constexpr (TBU > 1) step(bufc, nbufc, pbc, std::integral_constant<int, 1>{});
+            if constexpr (TBU > 2) step(bufc, nbufc, pbc, std::integral_constant<int, 2>{});
+            if constexpr (TBU > 3) step(bufc, nbufc, pbc, std::integral_constant<int, 3>{});
+            if constexpr (TBU > 4) step(bufc, nbufc, pbc, std::integral_constant<int, 4>{});
+            if constexpr (TBU > 5) step(bufc, nbufc, pbc, std::integral_constant<int, 5>{});
+            if constexpr (TBU > 6) step(bufc, nbufc, pbc, std::integral_constant<int, 6>{});
             advance();
         };
         load_b(B0{});
-        load_a(B0{}, std::integral_constant<int, 0>{});
-        if constexpr (TBU > 1) load_a(B0{}, std::integral_constant<int, 1>{});
-        if constexpr (TBU > 2) load_a(B0{}, std::integral_constant<int, 2>{});
-        if constexpr (TBU > 3) load_a(B0{}, std::integral_constant<int, 3>{});
-        if constexpr (TBU > 4) load_a(B0{}, std::integral_constant<int, 4>{});
-        if constexpr (TBU > 5) load_a(B0{}, std::integral_constant<int, 5>{});
-        if constexpr (TBU > 6) load_a(B0{}, std::integral_constant<int, 6>{});
+        load_a(B0{}, 0, std::integral_constant<int, 0>{});
         advance();
         __builtin_amdgcn_sched_barrier(0);
         for (int k = 0; k < NU; k += 2) {
-            unit(B0{}, B1{});
-            if (k + 1 < NU) unit(B1{}, B0{});
+            unit(B0{}, B1{}, std::integral_constant<int, 0>{});                 // taps 0 .. TBU-1: A parity starts at 0
+            if (k + 1 < NU) unit(B1{}, B0{}, std::integral_constant<int, TBU & 1>{});
         }
     };
 
