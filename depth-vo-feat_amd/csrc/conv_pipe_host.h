@@ -170,7 +170,9 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     // faster (tools/conv_bench.py, round 1).  They stay on that kernel until the patch is staged in 16-byte lanes.
     // (tried in round 1: staging the patch in 16-byte lanes -- 4x SLOWER than 4-byte lanes for these short row-strided
     // runs, loads-only 82 us vs 30 us on the 3x3 128->128 @32x104 layer -- so that is not the way to bring them over)
-    if (a.M <= 32 && !ov.on) return DVF_ERR_UNSUPPORTED;
+    // (measured per layer with tools/conv_bench.py: at 17..32 channels the pipelined kernel still wins for the 5x5 / 7x7
+    // kernels and for the output-parity classes of stride-2 layers, where a chunk carries many taps per staged byte)
+    if (a.M <= 32 && !ov.on && !(a.M > 16 && (ncls > 1 || Tmax >= 25))) return DVF_ERR_UNSUPPORTED;
     if (ov.on && ov.KS < 0) return DVF_ERR_UNSUPPORTED;      // (tuning: force the gather kernel)
     int maxc = 0;
     for (int s = 0; s < a.nseg; ++s) maxc = a.segC[s] > maxc ? a.segC[s] : maxc;
