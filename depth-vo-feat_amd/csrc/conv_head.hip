@@ -38,6 +38,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
                                                        int W, int tilesX, int act, float alpha, float beta, int ws_m, int ws_c,
                                                        int flip) {
     __shared__ float tile[HCK * FP_N];
+    extern __shared__ float wsh[];           // [MO][C][9] weights of the block (tap order already flipped if asked)
+    for (int e = threadIdx.x; e < MO * C * 9; e += 256) {
+        const int m = e / (C * 9), r = e - m * (C * 9), c = r / 9, k = r - c * 9;
+        wsh[e] = w[(int64_t)m * ws_m + (int64_t)c * ws_c + (flip ? 8 - k : k)];
+    }
     const int n = blockIdx.y, tY = blockIdx.x / tilesX, tX = blockIdx.x - tY * tilesX;
     const int y0 = tY * FT_H, x0 = tX * HT_W;
     const int lx = threadIdx.x & (HT_W - 1), ly = (threadIdx.x >> 6) * 2;      // rows ly, ly+1
@@ -52,15 +57,19 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
     float acc[2][MO];
 #pragma unroll
     for (int m = 0; m < MO; ++m) acc[0][m] = acc[1][m] = bias ? bias[m] : 0.f;
-    for (int c0 = 0; c0 < C; c0 += HCK) {
+    // the loads of chunk c0 + HCK are issued before the FMAs of chunk c0 (registers), so their latency overlaps them
+    float stg[HCK][F_LD];
+    auto issue = [&](int c0) {
         const int nch = min(HCK, C - c0);
         const float *src = in + ((int64_t)n * C + c0) * plane;
-        // all loads of the chunk first (independent, in flight together), then the LDS stores
-        float stg[HCK][F_LD];
 #pragma unroll
         for (int ch = 0; ch < HCK; ++ch)
 #pragma unroll
             for (int i = 0; i < F_LD; ++i) stg[ch][i] = (ch < nch && soff[i] >= 0) ? src[ch * plane + soff[i]] : 0.f;
+    };
+    issue(0);
+    for (int c0 = 0; c0 < C; c0 += HCK) {
+        const int nch = min(HCK, C - c0);
         __syncthreads();
 #pragma unroll
         for (int ch = 0; ch < HCK; ++ch)
@@ -70,6 +79,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
                 if (e < FP_N) tile[ch * FP_N + e] = stg[ch][i];
             }
         __syncthreads();
+        if (c0 + HCK < C) issue(c0 + HCK);
         for (int ch = 0; ch < nch; ++ch) {
             const float *t = tile + ch * FP_N + ly * HP_W + lx;
             float v[4][3];
@@ -79,10 +89,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
                 for (int b = 0; b < 3; ++b) v[a][b] = t[a * HP_W + b];
 #pragma unroll
             for (int m = 0; m < MO; ++m) {
-                const float *wm = w + (int64_t)m * ws_m + (int64_t)(c0 + ch) * ws_c;        // uniform address: scalar loads
+                const float *wm = wsh + (m * C + c0 + ch) * 9;             // LDS broadcast reads
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    const float wk = flip ? wm[8 - k] : wm[k];
+                    const float wk = wm[k];
                     acc[0][m] = fmaf(wk, v[k / 3][k % 3], acc[0][m]);
                     acc[1][m] = fmaf(wk, v[k / 3 + 1][k % 3], acc[1][m]);
                 }
@@ -195,7 +205,8 @@ inline int cdivh(int a, int b) { return (a + b - 1) / b; }
 
 bool dvf_head_applicable(const dvf_conv_desc *d, int nseg) {
     return nseg == 1 && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->C_out >= 1 &&
-           d->C_out <= 4 && d->H_out == d->H_in && d->W_out == d->W_in && d->C_in >= 4 && getenv("DVF_NO_HEAD") == nullptr;
+           d->C_out <= 4 && d->H_out == d->H_in && d->W_out == d->W_in && d->C_in >= 4 && d->C_in * d->C_out <= 1024 &&
+           getenv("DVF_NO_HEAD") == nullptr;
 }
 
 #define HEAD_DISPATCH(MOV, CALL)                 \
@@ -210,8 +221,8 @@ bool dvf_head_applicable(const dvf_conv_desc *d, int nseg) {
 int dvf_head_fwd(const dvf_conv_desc *d, const float *in, const float *w, const float *bias, float *out, hipStream_t st) {
     const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, FT_H);
     const dim3 grid(tilesX * tilesY, d->N);
-    HEAD_DISPATCH(d->C_out, (head_fwd_kernel<MO><<<grid, 256, 0, st>>>(in, w, bias, out, d->C_in, d->H_in, d->W_in, tilesX,
-                                                                      d->act, d->alpha, d->beta, d->C_in * 9, 9, 0)));
+    HEAD_DISPATCH(d->C_out, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_in * 9 * 4, st>>>(
+                                 in, w, bias, out, d->C_in, d->H_in, d->W_in, tilesX, d->act, d->alpha, d->beta, d->C_in * 9, 9, 0)));
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }
@@ -221,7 +232,8 @@ int dvf_head_fwd(const dvf_conv_desc *d, const float *in, const float *w, const 
 // = the head forward over dpre with transposed, tap-flipped weights.
 bool dvf_head_seg_dgrad_applicable(const dvf_conv_desc *d, int segc) {
     return !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && segc >= 1 && segc <= 4 &&
-           d->H_out == d->H_in && d->W_out == d->W_in && d->C_out >= 4 && getenv("DVF_NO_HEAD") == nullptr;
+           d->H_out == d->H_in && d->W_out == d->W_in && d->C_out >= 4 && d->C_out * segc <= 1024 &&
+           getenv("DVF_NO_HEAD") == nullptr;
 }
 
 int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int seg_off, int segc,
@@ -229,8 +241,8 @@ int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w
     const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, FT_H);
     const dim3 grid(tilesX * tilesY, d->N);
     const float *wseg = w + (int64_t)seg_off * 9;
-    HEAD_DISPATCH(segc, (head_fwd_kernel<MO><<<grid, 256, 0, st>>>(dpre, wseg, nullptr, din, d->C_out, d->H_in, d->W_in, tilesX,
-                                                                  DVF_ACT_NONE, 1.f, 0.f, 9, d->C_in * 9, 1)));
+    HEAD_DISPATCH(segc, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_out * 9 * 4, st>>>(
+                             dpre, wseg, nullptr, din, d->C_out, d->H_in, d->W_in, tilesX, DVF_ACT_NONE, 1.f, 0.f, 9, d->C_in * 9, 1)));
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }

@@ -18,6 +18,9 @@ LAYERS = [  # name, cin segs, cout, k, s, p, op, transposed, act, (N,H,W), out_h
     ("iconv2 3x3s1 65->32 @128x416", [32, 32, 1], 32, 3, 1, 1, 0, False, 1, (4, 128, 416), None),
     ("iconv1 3x3s1 17->16 @256x832", [16, 1], 16, 3, 1, 1, 0, False, 1, (4, 256, 832), None),
     ("disp1 3x3s1 16->1 @256x832", [16], 1, 3, 1, 1, 0, False, 2, (4, 256, 832), None),
+    ("disp2 3x3s1 32->1 @128x416", [32], 1, 3, 1, 1, 0, False, 2, (4, 128, 416), None),
+    ("disp3 3x3s1 64->1 @64x208", [64], 1, 3, 1, 1, 0, False, 2, (4, 64, 208), None),
+    ("disp4 3x3s1 128->1 @32x104", [128], 1, 3, 1, 1, 0, False, 2, (4, 32, 104), None),
     ("upconv4 T3x3s2 256->128 ->32x104", [256], 128, 3, 2, 1, 1, True, 1, (4, 16, 52), None),
     ("upconv2 T3x3s2 64->32 ->128x416", [64], 32, 3, 2, 1, 1, True, 1, (4, 64, 208), None),
     ("upconv1 T3x3s2 32->16 ->256x832", [32], 16, 3, 2, 1, 1, True, 1, (4, 128, 416), None),
