@@ -142,7 +142,10 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=832)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step from one HIP graph instead of eager launches (measured slower on MI355X: "
+                         "10.35 vs 9.62 ms/step at cfg 2 -- the multi-stream graph serialises more than the streams do)")
+    ap.add_argument("--no-graph", action="store_true", help="(default since round 1) eager launches")
     ap.add_argument("--force-ddp", action="store_true", help="run the multi-GPU exchange path even with one rank")
     ap.add_argument("--graph-ddp", action="store_true",
                     help="multi-GPU: replay forward+backward from a HIP graph and all-reduce afterwards (no overlap); "
@@ -175,8 +178,9 @@ def main():
         from dvf import lib as _L
         _L.SERIALIZE = True
     log("building models")
-    if (world > 1 or args.force_ddp) and not args.graph_ddp:
-        args.no_graph = True
+    args.no_graph = not args.graph
+    if (world > 1 or args.force_ddp) and args.graph_ddp:
+        args.no_graph = False
     step, fwd_bwd, opt, ddp = build(args, device, world)
     use_graph = not args.no_graph
     from dvf.engine import GraphedStep
