@@ -143,9 +143,11 @@ def main():
     ap.add_argument("--width", type=int, default=832)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--graph", action="store_true",
-                    help="replay the whole step from one HIP graph instead of eager launches (measured slower on MI355X: "
-                         "10.35 vs 9.62 ms/step at cfg 2 -- the multi-stream graph serialises more than the streams do)")
-    ap.add_argument("--no-graph", action="store_true", help="(default since round 1) eager launches")
+                    help="replay the whole step from one HIP graph (10.35 ms/step at cfg 2 on the round-1 box)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="eager launches on three streams (9.62 ms/step there; the host enqueues a step in 7.2 ms)")
+    # default (neither flag, one GPU): both are built, each is timed for a few untimed steps, the faster one is used --
+    # which of the two wins depends on how fast the host enqueues ~360 launches per step
     ap.add_argument("--force-ddp", action="store_true", help="run the multi-GPU exchange path even with one rank")
     ap.add_argument("--graph-ddp", action="store_true",
                     help="multi-GPU: replay forward+backward from a HIP graph and all-reduce afterwards (no overlap); "
@@ -178,13 +180,32 @@ def main():
         from dvf import lib as _L
         _L.SERIALIZE = True
     log("building models")
-    args.no_graph = not args.graph
-    if (world > 1 or args.force_ddp) and args.graph_ddp:
-        args.no_graph = False
+    auto = not args.graph and not args.no_graph and world == 1 and not args.force_ddp and not args.serialize
+    if world > 1 or args.force_ddp:
+        args.no_graph = not args.graph_ddp
+    elif not args.graph:
+        args.no_graph = True
     step, fwd_bwd, opt, ddp = build(args, device, world)
     use_graph = not args.no_graph
     from dvf.engine import GraphedStep
-    if use_graph:
+    if auto:
+        def clock(fn, k=6):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(k):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / k
+        t_eager = clock(step)
+        graphed = GraphedStep(step, [], warmup=1)
+        t_graph = clock(graphed)
+        use_graph = t_graph < t_eager
+        log("launch mode: eager %.2f ms/step, HIP graph %.2f ms/step -> %s" % (1e3 * t_eager, 1e3 * t_graph,
+                                                                            "graph" if use_graph else "eager"))
+        run = graphed if use_graph else step
+    elif use_graph:
         log("eager step 1")
         step()
         torch.cuda.synchronize()
