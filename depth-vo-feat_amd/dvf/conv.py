@@ -33,7 +33,7 @@ _WS = {}      # (device, stream) -> split-K scratch shared by the convolutions o
 def _workspace(nfloats, device):
     """Scratch for split-K partial tiles: one buffer per compute stream (kernels of one stream are ordered, so they can
     share it); it only grows (in the eager warm-up steps, never inside a graph capture)."""
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, L.stream().value)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
         if torch.cuda.is_current_stream_capturing():

