@@ -54,11 +54,21 @@ def repack_all():
     lib = L.lib()
     live = [(r, r[0]()) for r in _PACK_REGISTRY]
     live = [(r, w) for r, w in live if w is not None]
+    if len(live) != len(_PACK_REGISTRY) and not torch.cuda.is_current_stream_capturing():
+        _PACK_REGISTRY[:] = [r for r, _ in live]          # drop the layers of models that no longer exist
     t = _PACK_TABLE
     key = tuple((id(r), w.data_ptr()) for r, w in live)
     if t.get("key") != key:
         if torch.cuda.is_current_stream_capturing():
-            return                                  # (table changes are picked up by the per-layer path)
+            # the set of live layers changed since the table was built (e.g. another model was garbage-collected) and a
+            # table cannot be uploaded inside a capture: record one pack launch per layer instead -- a captured step
+            # must refresh the copies on every replay
+            for r, w in live:
+                _, desc, segc, kind, ent = r
+                L.check(lib.dvf_conv2d_pack(ctypes.byref(desc), L.int_array(segc), len(segc), kind, L.dev(w), L.dev(ent[0]),
+                                            L.stream()), "dvf_conv2d_pack")
+                ent[1] = (w.data_ptr(), w._version, L.PACK_EPOCH)
+            return
         blobs, blocks, lds = [], [], ctypes.c_int(4)
         for r, w in live:
             _, desc, segc, kind, ent = r
@@ -74,6 +84,8 @@ def repack_all():
         prefix = [0]
         for b in blocks:
             prefix.append(prefix[-1] + b)
+        # (earlier tables stay allocated: a captured graph may still launch with them)
+        t.setdefault("keep", []).append((t.get("jobs"), t.get("prefix")))
         t["jobs"] = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev)
         t["prefix"] = torch.tensor(prefix, dtype=torch.int32, device=dev)
         t["njobs"], t["total"], t["lds"], t["key"] = len(blocks), prefix[-1], lds.value, key
