@@ -1,9 +1,8 @@
 """Shared plumbing of the entry scripts (train.py / unsupervise.py / unsupervise_dvo.py): process-group setup,
 synthetic data stream, the step loop with device-side loss accumulation, checkpoints in the reference's format.
 
-The reference's datasets (un_dataset.py, dataset.py) need KITTI on disk, `path`, `cv2` and the removed
-`scipy.misc` API and are out of scope: the scripts run on the seeded synthetic
-stream that the benchmark uses (``--synthetic`` is implied and is the only data source)."""
+Data: the seeded synthetic stream that the benchmark uses by default; with ``--data-root`` the stereo-sequence listing
+of the reference's un_dataset.py is read through this build's PIL-based ``un_dataset.dataset``."""
 import os
 import time
 
@@ -16,7 +15,11 @@ from .synthetic import synthetic_batch
 
 def add_common_flags(parser):
     g = parser.add_argument_group("MI355X build extensions")
-    g.add_argument("--synthetic", action="store_true", default=True, help="seeded synthetic KITTI-shaped data (the only source)")
+    g.add_argument("--synthetic", action="store_true", default=True,
+                   help="seeded synthetic KITTI-shaped data (used when no --data-root listing is given)")
+    g.add_argument("--data-root", default=None,
+                   help="directory laid out like the reference's data/kitti_eigen (train.txt, intrinsics/, train_K/, "
+                        "train_T_R2L/): read through un_dataset.dataset; each rank takes every world-th sample")
     g.add_argument("--height", type=int, default=256)
     g.add_argument("--width", type=int, default=832)
     g.add_argument("--steps-per-epoch", type=int, default=50, help="synthetic iterations per epoch")
@@ -60,6 +63,22 @@ def run_training(args, nets, loss_fn, lr, betas, weight_decay, term_names, ckpt_
     opt = FlatAdam(params, lr=lr, betas=betas, weight_decay=weight_decay, world_size=world, overlap=True)
     batch = synthetic_batch(args.batch_size, args.height, args.width, seed=1234 + args.seed, rank=rank, n_views=n_views,
                             device=device)
+    # real data: un_dataset.dataset -> DataLoader (sharded by rank); every step copies the next batch INTO the static
+    # input tensors, so the step (eager or graph replay) always reads the same addresses
+    feed = None
+    if getattr(args, "data_root", None):
+        import un_dataset
+        ds = un_dataset.dataset(img_height=args.height, img_width=args.width, root=args.data_root, seed=args.seed)
+        idx = list(range(rank, len(ds), world))
+        loader = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, idx), batch_size=args.batch_size, shuffle=True,
+                                             num_workers=getattr(args, "workers", 0), drop_last=True, pin_memory=True)
+        args.steps_per_epoch = max(1, len(loader))
+
+        def feed():
+            while True:
+                for sample in loader:
+                    yield un_dataset.to_batch(sample, device)
+        feed = feed()
     acc = torch.zeros(len(term_names), device=device)            # device-side running sums: no per-step .item()
 
     def step():
@@ -79,6 +98,10 @@ def run_training(args, nets, loss_fn, lr, betas, weight_decay, term_names, ckpt_
         acc.zero_()
         t0 = time.perf_counter()
         for it in range(args.steps_per_epoch):
+            if feed is not None:
+                nxt = next(feed)
+                for k in ("img_R2", "img_R1", "img_L2", "K", "Kinv", "T_R2L"):
+                    batch[k].copy_(nxt[k].reshape(batch[k].shape), non_blocking=True)
             runner()
             # a fresh synthetic batch every step would only change values, not the work; new data is copied into the
             # static input tensors in place (graph replay reads the same addresses)

@@ -1,0 +1,102 @@
+"""Stereo-sequence dataset for unsupervise.py / unsupervise_dvo.py -- the reference's ``pytorch_version/un_dataset.py``
+without its dead dependencies (``path``, and ``scipy.misc.imread/imresize`` which SciPy removed): PIL does the decoding
+and the resize that scipy.misc delegated to it.
+
+Same sample definition and return tuple (un_dataset.py:43-84): a line of the listing names left_1 left_2 right_1 right_2
+and the ids of the raw K and of T_R2L; __getitem__ returns float32 tensors
+    (img_R1, img_L2, img_R2 [3,H,W] in 0..255, intrinsics [3,3], inv(intrinsics) [3,3], raw_K, T_R2L)
+The reference hard-codes /home/gaof/... (un_dataset.py:21-22); here the root and listing are arguments, with the same
+layout underneath: <root>/train.txt, <root>/intrinsics/<drive>_cam.txt, <root>/train_K/<id>.npy, <root>/train_T_R2L/<id>.npy.
+
+scipy.misc.imresize quirk kept on purpose: it was called on the float32 image, and for a non-uint8 array scipy's
+``toimage`` first rescaled [min, max] of the image to [0, 255] (``bytescale``) before the bilinear resize to uint8."""
+import os
+import random
+
+import numpy as np
+import torch
+import torch.utils.data as data
+from PIL import Image
+
+SKIPPED_DRIVE = "2011_09_26_drive_0060_sync"        # un_dataset.py:28 (a static scene)
+
+
+def imread(path):
+    """HxWx3 uint8, like scipy.misc.imread on an RGB file."""
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"))
+
+
+def bytescale(arr):
+    """scipy.misc.bytescale with its defaults (cmin=min, cmax=max, low=0, high=255) as imresize applied it."""
+    arr = np.asarray(arr)
+    if arr.dtype == np.uint8:
+        return arr
+    cmin, cmax = float(arr.min()), float(arr.max())
+    cscale = cmax - cmin
+    if cscale == 0:
+        cscale = 1.0
+    scaled = (arr - cmin) * (255.0 / cscale)
+    return (scaled.clip(0, 255) + 0.5).astype(np.uint8)
+
+
+def imresize(arr, size):
+    """scipy.misc.imresize(arr, (H, W)) with its default interp='bilinear': PIL resize of the byte-scaled image."""
+    im = Image.fromarray(bytescale(arr))
+    return np.asarray(im.resize((int(size[1]), int(size[0])), resample=Image.BILINEAR))
+
+
+class dataset(data.Dataset):
+    def __init__(self, transform=None, seed=9999, img_height=160, img_width=608, shuffle=True,
+                 root="./data/kitti_eigen", listing=None):
+        np.random.seed(seed)
+        random.seed(seed)
+        self.shuffle = shuffle
+        self.transform = transform
+        self.height, self.width = img_height, img_width
+        self.root = root
+        self.listing = listing if listing is not None else os.path.join(root, "train.txt")
+        self.generator()
+
+    def generator(self):
+        self.samples = []
+        with open(self.listing) as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) < 6:
+                    continue
+                l1, l2, r1, r2, k, t = parts[:6]
+                drive = l1.split("/")[-4]
+                if drive == SKIPPED_DRIVE:
+                    continue
+                self.samples.append({
+                    "left_1": l1, "left_2": l2, "right_1": r1, "right_2": r2,
+                    "intrinsics": os.path.join(self.root, "intrinsics", drive + "_cam.txt"),
+                    "raw_K": os.path.join(self.root, "train_K", k + ".npy"),
+                    "T_R2L": os.path.join(self.root, "train_T_R2L", t + ".npy"),
+                })
+
+    def __getitem__(self, index):
+        s = self.samples[index]
+        imgs = [imread(s[k]).astype(np.float32) for k in ("right_1", "left_2", "right_2")]
+        imgs = [imresize(im, (self.height, self.width)).astype(np.float32) for im in imgs]
+        intrinsics = np.genfromtxt(s["intrinsics"]).astype(np.float32).reshape((3, 3))
+        raw_K = np.load(s["raw_K"], allow_pickle=False).astype(np.float32)
+        T_R2L = np.load(s["T_R2L"], allow_pickle=False).astype(np.float32)
+        if self.transform is not None:
+            imgs = [self.transform(im).numpy() for im in imgs]
+        else:
+            imgs = [np.transpose(im, (2, 0, 1)) for im in imgs]
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).type(torch.FloatTensor)
+        return (f32(imgs[0]), f32(imgs[1]), f32(imgs[2]), f32(intrinsics), f32(np.linalg.inv(intrinsics)), f32(raw_K),
+                f32(T_R2L))
+
+    def __len__(self):
+        return len(self.samples)
+
+
+def to_batch(sample_batch, device):
+    """Collated dataset output -> the batch dict of dvf/steps.py (device tensors)."""
+    r1, l2, r2, K, Kinv, raw_K, T = [x.to(device, non_blocking=True) for x in sample_batch]
+    return {"img_R1": r1.contiguous(), "img_L2": l2.contiguous(), "img_R2": r2.contiguous(), "K": K.contiguous(),
+            "Kinv": Kinv.contiguous(), "raw_K": raw_K, "T_R2L": T.reshape(T.shape[0], -1)[:, :6].contiguous()}

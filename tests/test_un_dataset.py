@@ -1,0 +1,66 @@
+"""un_dataset.dataset on a synthetic KITTI-shaped directory.  The reference loader needs `path` and the
+removed scipy.misc API and cannot be imported: its semantics (incl. the float -> bytescale quirk of imresize) are
+restated; parity unpinned."""
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+import un_dataset
+
+
+def _make_tree(tmp_path, n=3):
+    root = tmp_path / "kitti_eigen"
+    for d in ("intrinsics", "train_K", "train_T_R2L"):
+        (root / d).mkdir(parents=True)
+    rng = np.random.default_rng(5)
+    lines = []
+    for drive in ("2011_09_26_drive_0001_sync", un_dataset.SKIPPED_DRIVE):
+        for cam in ("image_02", "image_03"):
+            (tmp_path / "raw" / "2011_09_26" / drive / cam / "data").mkdir(parents=True)
+        K = np.array([[700.0, 0, 600], [0, 710.0, 180], [0, 0, 1]])
+        np.savetxt(root / "intrinsics" / (drive + "_cam.txt"), K.reshape(1, 9))
+        for i in range(n):
+            paths = []
+            for cam, j in (("image_02", i), ("image_02", i + 1), ("image_03", i), ("image_03", i + 1)):
+                p = tmp_path / "raw" / "2011_09_26" / drive / cam / "data" / f"{j:010d}.png"
+                if not p.exists():
+                    img = rng.integers(20, 200, size=(37, 123, 3), dtype=np.uint8)      # min > 0, max < 255: bytescale acts
+                    Image.fromarray(img).save(p)
+                paths.append(str(p))
+            kid = f"{drive[-9:-5]}_{i}"
+            np.save(root / "train_K" / (kid + ".npy"), K.astype(np.float64))
+            np.save(root / "train_T_R2L" / (kid + ".npy"), np.array([[-0.54, 0, 0, 0, 0, 0]]))
+            lines.append(" ".join(paths + [kid, kid]))
+    (root / "train.txt").write_text("\n".join(lines) + "\n")
+    return root
+
+
+def test_dataset_samples_and_resize_semantics(tmp_path):
+    root = _make_tree(tmp_path)
+    ds = un_dataset.dataset(img_height=16, img_width=48, root=str(root))
+    assert len(ds) == 3                                      # the static drive is skipped
+    r1, l2, r2, K, Kinv, raw_K, T = ds[1]
+    for t in (r1, l2, r2):
+        assert t.dtype == torch.float32 and tuple(t.shape) == (3, 16, 48)
+        assert float(t.min()) >= 0 and float(t.max()) <= 255
+    assert torch.allclose(K @ Kinv, torch.eye(3), atol=1e-3)      # (fp32 inverse, as in the reference)
+    assert tuple(raw_K.shape) == (3, 3) and tuple(T.shape) == (1, 6) and float(T[0, 0]) == np.float32(-0.54)
+    # the resize is PIL's bilinear on the byte-scaled image
+    src = un_dataset.imread(ds.samples[1]["right_1"]).astype(np.float32)
+    lo, hi = src.min(), src.max()
+    manual = np.asarray(Image.fromarray(((src - lo) * (255.0 / (hi - lo)) + 0.5).clip(0, 255.5).astype(np.uint8))
+                        .resize((48, 16), resample=Image.BILINEAR)).astype(np.float32)
+    assert np.array_equal(r1.numpy(), manual.transpose(2, 0, 1))
+    # uint8 input is not rescaled
+    assert np.array_equal(un_dataset.bytescale(np.arange(10, dtype=np.uint8)), np.arange(10, dtype=np.uint8))
+
+
+def test_loader_and_batch_dict(tmp_path):
+    root = _make_tree(tmp_path)
+    ds = un_dataset.dataset(img_height=16, img_width=48, root=str(root))
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=0)
+    batch = un_dataset.to_batch(next(iter(loader)), "cpu")
+    assert tuple(batch["img_R2"].shape) == (2, 3, 16, 48) and tuple(batch["K"].shape) == (2, 3, 3)
+    assert tuple(batch["T_R2L"].shape) == (2, 6) and batch["img_L2"].is_contiguous()
