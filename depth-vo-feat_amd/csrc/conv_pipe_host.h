@@ -58,14 +58,40 @@ __device__ __forceinline__ void pack_block(const PackArgs &a, int g, int mt, flo
         }
     }
     __syncthreads();
-    // destination order without divisions: a thread keeps its (lane, channel pair) and walks (unit, tap) incrementally
+    // destination order without divisions: a thread keeps its lane (and channel pair) and walks (unit, tap) incrementally
     const int CKH = a.CK >> 1, CPG = CKH / a.VW, LV = 64 * a.VW;       // LV in {128, 256}
+    if (a.VW == 4) {
+        // 16-byte stores: a thread owns one lane's four channel pairs of a (unit, tap); 4 (unit, tap) rows per pass
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int lane = tid & 63, kh = lane >> 5, m = lane & 31;
+        for (int c = 0; c < a.ncls; ++c) {
+            const int TB = a.TB[c], NKU = a.TA[c] * CPG * a.TBU;
+            float *dst = a.wp + a.wp_off[c] + (int64_t)(mb * a.NCH + g) * a.SL[c] + (int64_t)mtw * 256 + lane * 4;
+            int ku = tid >> 6, u = ku, cpg = 0, ta = 0;
+            while (u >= a.TBU) { u -= a.TBU; if (++cpg == CPG) { cpg = 0; ++ta; } }
+            for (; ku < NKU; ku += 4) {
+                f4 v = {0.f, 0.f, 0.f, 0.f};
+                if (u < TB && m < mvalid) {
+                    const float *src = S + m * CKK + a.tapmap[c][ta * TB + u];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int rl = 2 * (cpg * 4 + j) + kh;
+                        if (rl < nch) v[j] = src[rl * a.KK];
+                    }
+                }
+                *reinterpret_cast<f4 *>(dst + (int64_t)ku * MTW * 256) = v;
+                u += 4;
+                while (u >= a.TBU) { u -= a.TBU; if (++cpg == CPG) { cpg = 0; ++ta; } }
+            }
+        }
+        return;
+    }
     const int x = tid & (LV - 1), kstep = 256 / LV;
     const int lane = x / a.VW, j = x - lane * a.VW, kh = lane >> 5, m = lane & 31;
     for (int c = 0; c < a.ncls; ++c) {
         const int TB = a.TB[c], NKU = a.TA[c] * CPG * a.TBU;
         float *dst = a.wp + a.wp_off[c] + (int64_t)(mb * a.NCH + g) * a.SL[c] + (int64_t)mtw * LV + x;
-        int ku = tid / LV, u = ku, cpg = 0, ta = 0;       // ku = (ta*CPG + cpg)*TBU + u ; first ku < kstep <= 2 <= TBU... 
+        int ku = tid / LV, u = ku, cpg = 0, ta = 0;       // ku = (ta*CPG + cpg)*TBU + u
         while (u >= a.TBU) { u -= a.TBU; if (++cpg == CPG) { cpg = 0; ++ta; } }
         for (; ku < NKU; ku += kstep) {
             const int rl = 2 * (cpg * a.VW + j) + kh;
