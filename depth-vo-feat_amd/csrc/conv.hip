@@ -320,6 +320,7 @@ struct WgradArgs {
     int N, GH, GW, QH, QW, S, pad;
     int CK, BH, lnp, tilesX, tilesY, PSPLIT;
     int PHq, PWq, PWH, RS, PS, COTP;
+    int vp;              // P tile loaded in 16-byte lanes (GW % 4 == 0, 16-byte aligned base)
 };
 
 constexpr int WG_BW = 32;
@@ -404,7 +405,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 }
             }
         }
-        {   // P tile: item idx = (channel m, row pair rp); half-wave = one row of 32 pixels
+        if (a.vp) {
+            // P tile in 16-byte lanes: instruction k of this wave = image row (k' % BH) of the 8 channels 8*(k'/BH)..+7,
+            // k' = wave + 4k; lane = (channel seg = lane >> 3, pixel group q = lane & 7 -> pixels 4q..4q+3).  4x fewer
+            // vector-memory instructions than one float per lane: this kernel is bound by their issue rate.
+            const int seg = lane >> 3, q = lane & 7;
+            const unsigned plane = (unsigned)(a.GH * a.GW) << 2;
+            const bool colok = gx0 + 4 * q < a.GW;                       // (GW % 4 == 0: a group is all in or all out)
+            const unsigned pb = (unsigned)((n * a.PCtot + a.m_base + m0) * a.GH * a.GW) << 2;
+            const unsigned lane_off = (unsigned)seg * plane + ((unsigned)(gx0 + 4 * q) << 2);
+            const int nitems = 4 * MT * a.BH;
+#pragma unroll
+            for (int k = 0; k < WG_PMAX / 4; ++k) {
+                const int it = wave + 4 * k, mg = it / a.BH, row = it - mg * a.BH;
+                const int gy = gy0 + row;
+                const bool ok = (it < nitems) & colok & (gy < a.GH) & (m0 + mg * 8 + seg < a.M);
+                const unsigned soff = pb + (unsigned)(mg * 8) * plane + ((unsigned)(gy * a.GW) << 2);
+                const auto v4 = __builtin_amdgcn_raw_buffer_load_b128(rs_p, ok ? lane_off : OOB, ok ? soff : 0u, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) preg[4 * k + j] = __builtin_bit_cast(float, v4[j]);
+            }
+        } else {   // P tile: item idx = (channel m, row pair rp); half-wave = one row of 32 pixels
             const int px = lane & 31, prow = lane >> 5;
             const bool colok = gx0 + px < a.GW;
             const unsigned pb = (unsigned)((n * a.PCtot + a.m_base + m0) * a.GH * a.GW) << 2;
@@ -432,7 +453,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 }
             }
         }
-        {
+        if (a.vp) {
+            const int seg = lane >> 3, q = lane & 7;
+            const int nitems = 4 * MT * a.BH;
+#pragma unroll
+            for (int k = 0; k < WG_PMAX / 4; ++k) {
+                const int it = wave + 4 * k, mg = it / a.BH, row = it - mg * a.BH;
+                if (it < nitems) {
+                    float *dst = pl + (row * WG_BW + 4 * q) * COTP + mg * 8 + seg;     // bank = 4q + j + seg: conflict-free
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dst[j * COTP] = preg[4 * k + j];
+                }
+            }
+        } else {
             const int px = lane & 31, prow = lane >> 5;
 #pragma unroll
             for (int k = 0; k < WG_PMAX; ++k) {
@@ -1030,6 +1063,8 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
         // register prefetch of the next tile when a wave's share of the Q patch fits the register budget (one pass)
         static const bool no_pf = getenv("DVF_WG_NOPF") != nullptr;
         const bool pf = !no_pf && a.PWq <= 64 && cdiv(CK * a.PHq, 4) <= 24 && 8 * MT * (a.BH >> 1) <= 16 * MT;
+        static const bool no_vp = getenv("DVF_WG_NOVP") != nullptr;
+        a.vp = (pf && !no_vp && a.GW % 4 == 0 && (reinterpret_cast<uintptr_t>(a.P) & 15) == 0) ? 1 : 0;
         if (pf) {
             if (MT == 2 && NTW == 2) conv_wgrad_kernel<2, 2, true><<<grid, 256, lds, st>>>(a);
             else if (MT == 2) conv_wgrad_kernel<2, 1, true><<<grid, 256, lds, st>>>(a);
