@@ -421,9 +421,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 const int gy = gy0 + row;
                 const bool ok = (it < nitems) & colok & (gy < a.GH) & (m0 + mg * 8 + seg < a.M);
                 const unsigned soff = pb + (unsigned)(mg * 8) * plane + ((unsigned)(gy * a.GW) << 2);
-                const auto v4 = __builtin_amdgcn_raw_buffer_load_b128(rs_p, ok ? lane_off : OOB, ok ? soff : 0u, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) preg[4 * k + j] = __builtin_bit_cast(float, v4[j]);
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const f4 v4 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, ok ? lane_off : OOB, ok ? soff : 0u, 0));
+                preg[4 * k + 0] = v4.x; preg[4 * k + 1] = v4.y; preg[4 * k + 2] = v4.z; preg[4 * k + 3] = v4.w;
             }
         } else {   // P tile: item idx = (channel m, row pair rp); half-wave = one row of 32 pixels
             const int px = lane & 31, prow = lane >> 5;
