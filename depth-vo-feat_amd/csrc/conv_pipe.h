@@ -100,11 +100,12 @@ template <> struct fvec<4> { typedef float type __attribute__((ext_vector_type(4
 // instruction streams instead of stalling an MFMA wave's.  Two or three LDS stages: chunk g+NST-1 is issued
 // while chunk g is consumed, and because each producer only ever has ONE chunk in flight, "my chunk has landed" is a
 // plain vmcnt(0).
-constexpr int PIPE_THREADS = 384;
+constexpr int PIPE_THREADS = 384;        // 4 MFMA waves + 2 producers; PIPE_THREADS_4P: + 4 producers (one per SIMD)
+constexpr int PIPE_THREADS_4P = 512;
 constexpr int PIPE_MAXNPI = 32;    // patch pieces per channel (per-channel patch <= 2048 floats)
 
 template <int MT, int NT, int WM, int CKH, int TBU>
-__global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs a) {
+__global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeArgs a) {
     constexpr int CK = 2 * CKH, VW = CKH >= 4 ? 4 : CKH, CPG = CKH / VW, MTW = MT * WM;
     constexpr int UNITF = TBU * MTW * 64 * VW;             // packed floats per unit
     typedef typename fvec<VW>::type avec;
@@ -126,7 +127,13 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs 
 
     if (wave >= 4) {
         // ================================================================== producer waves: all LDS-DMA loads
-        const int par = wave - 4;                          // this producer owns chunks g with (g - g_begin) % 2 == par
+        // Issuing an LDS-DMA instruction stalls the SIMD's issue port for ~60 cycles, which the MFMA wave sharing that
+        // SIMD loses (measured: full kernel = MFMA-only time + 25-30 % with two producers on SIMDs 0 and 1, while the
+        // block advances at the pace of its slowest MFMA wave).  Blocks that own a whole CU anyway are launched with FOUR
+        // producers, one per SIMD: producers 2*par and 2*par+1 share the chunks of parity `par`, half the pieces each.
+        const int nprod = (int)(blockDim.x >> 6) - 4, pidx = wave - 4;
+        const int par = nprod == 2 ? pidx : (pidx >> 1);   // this producer owns chunks x with x % 2 == par ...
+        const int half = nprod == 2 ? 0 : (pidx & 1), nhalf = nprod == 2 ? 1 : 2;     // ... and this share of their pieces
         const int NWP = c.SL >> 8;                         // 1 KiB weight pieces per chunk
         const int iy0 = oy0 * a.IS + c.by, ix0 = ox0 * a.IS + c.bx;
         unsigned pvoff[PIPE_MAXNPI];                       // per-lane source offset of every patch piece
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs 
             float *patch = wl + a.SLmax;
             if (!(a.dbg & 2)) {
                 const unsigned slab = (c.wp_off + (unsigned)(mb * a.NCH + g) * (unsigned)c.SL) << 2;
-                for (int p = 0; p < NWP; ++p)
+                for (int p = half; p < NWP; p += nhalf)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)(wl + (p << 8)), 16, (unsigned)lane << 4,
                                                              slab + ((unsigned)p << 10), 0, 0);
             }
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs 
                 const unsigned img = (unsigned)segc * plane;
                 const unsigned cb = (unsigned)(n0 * segc + c0) * plane;
                 // (no vector ALU work per piece: a VALU instruction costs the MFMA wave sharing this SIMD 6-8 cycles)
-                for (int ci = 0; ci < CK; ++ci) {
+                for (int ci = half; ci < CK; ci += nhalf) {
                     float *dst = patch + ci * PSR;
                     if (ci >= nch) {                       // channel tail of the segment: zero-fill
 #pragma unroll
@@ -410,11 +417,11 @@ __global__ __launch_bounds__(PIPE_THREADS) void conv_pipe_kernel(const PipeArgs 
 // Launch one (MT, NT, WM) family; CKH in {2,4,8} and TBU in {2,3,4} are dispatched inside.  Defined in the
 // conv_pipe_inst*.hip units (explicit specialisations), declared here for conv.hip.
 template <int MT, int NT, int WM>
-int launch_pipe_family(const PipeArgs &a, int CKH, int TBU, dim3 grid, size_t lds, hipStream_t st);
+int launch_pipe_family(const PipeArgs &a, int CKH, int TBU, dim3 grid, size_t lds, hipStream_t st, int threads);
 
 // blocks that use more than 64 KiB of LDS need the opt-in attribute (set once per kernel)
 template <int MT, int NT, int WM, int CKH, int TBU>
-inline int launch_pipe_one(const PipeArgs &a, dim3 grid, size_t lds, hipStream_t st) {
+inline int launch_pipe_one(const PipeArgs &a, dim3 grid, size_t lds, hipStream_t st, int threads) {
     static bool big_lds = false;
     if (lds > 64 * 1024 && !big_lds) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pipe_kernel<MT, NT, WM, CKH, TBU>),
@@ -422,30 +429,30 @@ inline int launch_pipe_one(const PipeArgs &a, dim3 grid, size_t lds, hipStream_t
             return DVF_ERR_LAUNCH;
         big_lds = true;
     }
-    conv_pipe_kernel<MT, NT, WM, CKH, TBU><<<grid, PIPE_THREADS, lds, st>>>(a);
+    conv_pipe_kernel<MT, NT, WM, CKH, TBU><<<grid, threads, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? DVF_OK : DVF_ERR_LAUNCH;
 }
 
 template <int MT, int NT, int WM, int CKH>
-inline int launch_pipe_tbu(const PipeArgs &a, int TBU, dim3 grid, size_t lds, hipStream_t st) {
+inline int launch_pipe_tbu(const PipeArgs &a, int TBU, dim3 grid, size_t lds, hipStream_t st, int threads) {
     switch (TBU) {
-        case 1: return launch_pipe_one<MT, NT, WM, CKH, 1>(a, grid, lds, st);
-        case 2: return launch_pipe_one<MT, NT, WM, CKH, 2>(a, grid, lds, st);
-        case 3: return launch_pipe_one<MT, NT, WM, CKH, 3>(a, grid, lds, st);
-        case 4: return launch_pipe_one<MT, NT, WM, CKH, 4>(a, grid, lds, st);
-        case 5: if constexpr (CKH <= 4 && WM == 1) return launch_pipe_one<MT, NT, WM, CKH, 5>(a, grid, lds, st); else return DVF_ERR_UNSUPPORTED;
-        case 7: if constexpr (CKH <= 4 && WM == 1) return launch_pipe_one<MT, NT, WM, CKH, 7>(a, grid, lds, st); else return DVF_ERR_UNSUPPORTED;
+        case 1: return launch_pipe_one<MT, NT, WM, CKH, 1>(a, grid, lds, st, threads);
+        case 2: return launch_pipe_one<MT, NT, WM, CKH, 2>(a, grid, lds, st, threads);
+        case 3: return launch_pipe_one<MT, NT, WM, CKH, 3>(a, grid, lds, st, threads);
+        case 4: return launch_pipe_one<MT, NT, WM, CKH, 4>(a, grid, lds, st, threads);
+        case 5: if constexpr (CKH <= 4 && WM == 1) return launch_pipe_one<MT, NT, WM, CKH, 5>(a, grid, lds, st, threads); else return DVF_ERR_UNSUPPORTED;
+        case 7: if constexpr (CKH <= 4 && WM == 1) return launch_pipe_one<MT, NT, WM, CKH, 7>(a, grid, lds, st, threads); else return DVF_ERR_UNSUPPORTED;
         default: return DVF_ERR_UNSUPPORTED;
     }
 }
 
 #define DVF_PIPE_FAMILY(MT, NT, WM)                                                                              \
     template <>                                                                                                  \
-    int launch_pipe_family<MT, NT, WM>(const PipeArgs &a, int CKH, int TBU, dim3 grid, size_t lds, hipStream_t st) { \
+    int launch_pipe_family<MT, NT, WM>(const PipeArgs &a, int CKH, int TBU, dim3 grid, size_t lds, hipStream_t st, int threads) { \
         switch (CKH) {                                                                                           \
-            case 2: return launch_pipe_tbu<MT, NT, WM, 2>(a, TBU, grid, lds, st);                                \
-            case 4: return launch_pipe_tbu<MT, NT, WM, 4>(a, TBU, grid, lds, st);                                \
-            case 8: return launch_pipe_tbu<MT, NT, WM, 8>(a, TBU, grid, lds, st);                                \
+            case 2: return launch_pipe_tbu<MT, NT, WM, 2>(a, TBU, grid, lds, st, threads);                                \
+            case 4: return launch_pipe_tbu<MT, NT, WM, 4>(a, TBU, grid, lds, st, threads);                                \
+            case 8: return launch_pipe_tbu<MT, NT, WM, 8>(a, TBU, grid, lds, st, threads);                                \
             default: return DVF_ERR_UNSUPPORTED;                                                                 \
         }                                                                                                        \
     }

@@ -136,7 +136,7 @@ __global__ void splitk_reduce_kernel(const float *ws, float *out, const float *b
 
 // ---------------------------------------------------------------------------------------- host planning
 struct PipePlan {
-    int MT, NT, WM, CKH, TBU;
+    int MT, NT, WM, CKH, TBU, threads;
     size_t lds;
     dim3 grid;
     int64_t packed_floats, ws_floats;
@@ -299,6 +299,12 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
         if ((int64_t)a.N * a.segC[s2] * a.IH * a.IW * 4 >= ((int64_t)1 << 31) - 16) return DVF_ERR_UNSUPPORTED;
     pl.MT = MT; pl.NT = NT; pl.WM = WM; pl.CKH = CK / 2; pl.TBU = TBU; pl.lds = lds_bytes(CK);
     pl.grid = dim3(a.tilesX * a.tilesY, mblocks, a.NG * KS * ncls);
+    // a block that has a CU to itself (by LDS size or by grid size) gets four producer waves, one per SIMD
+    {
+        const int64_t nblocks_total = (int64_t)pl.grid.x * pl.grid.y * pl.grid.z;
+        static const bool no4p = getenv("DVF_PIPE_NO4P") != nullptr;
+        pl.threads = (!no4p && (pl.lds > 76 * 1024 || nblocks_total <= 256)) ? dvfp::PIPE_THREADS_4P : dvfp::PIPE_THREADS;
+    }
     return DVF_OK;
 }
 
@@ -306,14 +312,14 @@ int launch_pipe(const PipeArgs &a, const PipePlan &pl, hipStream_t st) {
     using dvfp::launch_pipe_family;
     if (pl.WM == 2) {
         if (pl.NT != 1) return DVF_ERR_UNSUPPORTED;
-        return pl.MT == 2 ? launch_pipe_family<2, 1, 2>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st)
-                          : launch_pipe_family<1, 1, 2>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st);
+        return pl.MT == 2 ? launch_pipe_family<2, 1, 2>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st, pl.threads)
+                          : launch_pipe_family<1, 1, 2>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st, pl.threads);
     }
     if (pl.WM != 1) return DVF_ERR_UNSUPPORTED;
     if (pl.MT == 2 && pl.NT == 2) return DVF_ERR_UNSUPPORTED;
-    if (pl.MT == 2) return launch_pipe_family<2, 1, 1>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st);
-    if (pl.NT == 2) return launch_pipe_family<1, 2, 1>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st);
-    return launch_pipe_family<1, 1, 1>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st);
+    if (pl.MT == 2) return launch_pipe_family<2, 1, 1>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st, pl.threads);
+    if (pl.NT == 2) return launch_pipe_family<1, 2, 1>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st, pl.threads);
+    return launch_pipe_family<1, 1, 1>(a, pl.CKH, pl.TBU, pl.grid, pl.lds, st, pl.threads);
 }
 
 // One op instance = one (M range, reduction segments, classes) triple: Conv2d fwd, one segment of a dgrad, ...
