@@ -1044,7 +1044,8 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
         a.PS = a.PHq * a.RS;
         a.COTP = 32 * MT + 1;
         // keep the block's LDS (Q patch + transposed P tile) under 48 KiB: 3 blocks per CU
-        while (CK > 1 && ((size_t)CK * a.PS + (size_t)a.BH * WG_BW * a.COTP) * 4 > 48 * 1024) --CK;
+        static const size_t wg_lds_cap = (getenv("DVF_WG_LDS_KB") ? atoi(getenv("DVF_WG_LDS_KB")) : 52) * 1024;   // 3 blocks per CU (swept 36..60 KB on cfg 2)
+        while (CK > 1 && ((size_t)CK * a.PS + (size_t)a.BH * WG_BW * a.COTP) * 4 > wg_lds_cap) --CK;
         a.CK = CK;
         const int mtiles = cdiv(a.M, 32 * MT), cchunks = cdiv(a.Cq, CK);
         const int ntiles = a.N * a.tilesX * a.tilesY;
