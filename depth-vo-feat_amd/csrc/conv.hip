@@ -745,7 +745,8 @@ int plan_gather(GatherArgs &a, const ClassSpec *cls, int ncls, GatherPlan &pl) {
         return ((size_t)CK * a.PSmax + (size_t)Tmax * CK * COTP + WD + Tmax + 64) * 4;
     };
     int CK = 16;
-    while (CK > 2 && lds_bytes(CK) > 40 * 1024) CK >>= 1;
+    static const size_t g_lds_cap = (getenv("DVF_G_LDS_KB") ? atoi(getenv("DVF_G_LDS_KB")) : 40) * 1024;     // tuning knob
+    while (CK > 2 && lds_bytes(CK) > g_lds_cap) CK >>= 1;
     while (CK > 2 && CK / 2 >= maxc) CK >>= 1;
     if (lds_bytes(CK) > 64 * 1024) return DVF_ERR_UNSUPPORTED;
     a.WD = (a.w_mode == 0 ? CK : 32 * MT) * a.KK;
