@@ -1252,7 +1252,7 @@ int dvf_conv2d_pack_jobs(const dvf_conv_desc *d, const int *seg_channels, int ns
         if (r) return r;
         memset(out + (size_t)njobs * DVF_PACK_JOB_BYTES, 0, DVF_PACK_JOB_BYTES);
         memcpy(out + (size_t)njobs * DVF_PACK_JOB_BYTES, &job, sizeof(job));
-        if (lds_bytes_out) { const int l = 32 * job.CK * job.KK * 4; if (l > *lds_bytes_out) *lds_bytes_out = l; }
+        if (lds_bytes_out) { const int l = 32 * ((job.CK * job.KK) | 1) * 4; if (l > *lds_bytes_out) *lds_bytes_out = l; }
         ++njobs;
         return DVF_OK;
     };
@@ -1275,14 +1275,14 @@ int dvf_conv2d_pack_jobs(const dvf_conv_desc *d, const int *seg_channels, int ns
     return njobs;
 }
 
-int dvf_conv2d_pack_batch(const void *jobs_dev, const int *block_prefix_dev, int njobs, int total_blocks, int lds_bytes,
-                          void *stream) {
+int dvf_conv2d_pack_batch(const void *jobs_dev, const int *block_prefix_dev, const int *block_job_dev, int njobs,
+                          int total_blocks, int lds_bytes, void *stream) {
     if (!jobs_dev || !block_prefix_dev || njobs < 1 || total_blocks < 1 || lds_bytes < 4 || lds_bytes > 64 * 1024)
         return DVF_ERR_INVALID_ARG;
     static_assert(DVF_PACK_JOB_BYTES % alignof(PackArgs) == 0, "job stride");
     static_assert(sizeof(PackArgs) == DVF_PACK_JOB_BYTES, "job stride");
     conv_pack_batch_kernel<<<total_blocks, 256, lds_bytes, dvf_stream(stream)>>>(
-        static_cast<const PackArgs *>(jobs_dev), block_prefix_dev, njobs);
+        static_cast<const PackArgs *>(jobs_dev), block_prefix_dev, block_job_dev, njobs);
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }

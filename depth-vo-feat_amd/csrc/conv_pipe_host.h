@@ -39,22 +39,49 @@ __device__ __forceinline__ void pack_block(const PackArgs &a, int g, int mt, flo
     const int c0 = gg * a.CK, nch = min(a.CK, segc - c0), r0 = seg_start + c0;
     const int mvalid = min(32, a.M - m0);
     const int CKK = a.CK * a.KK;
-    const int wave = tid >> 6, lane64 = tid & 63;
+    const int SR = CKK | 1;                                // odd LDS row stride: the m-strided reads below hit 32 banks
+    // source -> LDS: the tile is walked as one flat index space, eight independent loads in flight per thread (a block
+    // moves only a few KB, so its run time is the latency of its dependent round trips to HBM)
+    constexpr int PU = 8;
     if (a.w_mode == 0) {
-        const int run = nch * a.KK;                        // contiguous floats per output channel
-        for (int m = wave; m < mvalid; m += 4) {
-            const float *src = a.w + ((int64_t)(a.m_base + m0 + m) * a.Rtot + r0) * a.KK;
-            for (int x = lane64; x < run; x += 64) S[m * CKK + x] = src[x];
+        const int run = nch * a.KK, total = mvalid * run;      // `run` contiguous floats per output channel
+        const float *src = a.w + ((int64_t)(a.m_base + m0) * a.Rtot + r0) * a.KK;
+        const int64_t mstride = (int64_t)a.Rtot * a.KK;
+        for (int i0 = tid; i0 < total; i0 += 256 * PU) {
+            float v[PU];
+            int si[PU];
+#pragma unroll
+            for (int j = 0; j < PU; ++j) {
+                const int i = i0 + j * 256;
+                if (i < total) {
+                    const int m = i / run, x = i - m * run;
+                    v[j] = src[m * mstride + x];
+                    si[j] = m * SR + x;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PU; ++j)
+                if (i0 + j * 256 < total) S[si[j]] = v[j];
         }
     } else {
-        const int run = mvalid * a.KK;                     // contiguous floats per reduction channel
-        const float invKK = 1.0f / (float)a.KK;
-        for (int rl = wave; rl < nch; rl += 4) {
-            const float *src = a.w + ((int64_t)(r0 + rl) * a.Mtot + a.m_base + m0) * a.KK;
-            for (int x = lane64; x < run; x += 64) {
-                const int m = (int)(((float)x + 0.5f) * invKK), tap = x - m * a.KK;    // exact for x < 2^12
-                S[m * CKK + rl * a.KK + tap] = src[x];
+        const int run = mvalid * a.KK, total = nch * run;      // `run` contiguous floats per reduction channel
+        const float *src = a.w + ((int64_t)r0 * a.Mtot + a.m_base + m0) * a.KK;
+        const int64_t rstride = (int64_t)a.Mtot * a.KK;
+        for (int i0 = tid; i0 < total; i0 += 256 * PU) {
+            float v[PU];
+            int si[PU];
+#pragma unroll
+            for (int j = 0; j < PU; ++j) {
+                const int i = i0 + j * 256;
+                if (i < total) {
+                    const int rl = i / run, x = i - rl * run, m = x / a.KK, tap = x - m * a.KK;
+                    v[j] = src[rl * rstride + x];
+                    si[j] = m * SR + rl * a.KK + tap;
+                }
             }
+#pragma unroll
+            for (int j = 0; j < PU; ++j)
+                if (i0 + j * 256 < total) S[si[j]] = v[j];
         }
     }
     __syncthreads();
@@ -72,7 +99,7 @@ __device__ __forceinline__ void pack_block(const PackArgs &a, int g, int mt, flo
             for (; ku < NKU; ku += 4) {
                 f4 v = {0.f, 0.f, 0.f, 0.f};
                 if (u < TB && m < mvalid) {
-                    const float *src = S + m * CKK + a.tapmap[c][ta * TB + u];
+                    const float *src = S + m * SR + a.tapmap[c][ta * TB + u];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int rl = 2 * (cpg * 4 + j) + kh;
@@ -96,7 +123,7 @@ __device__ __forceinline__ void pack_block(const PackArgs &a, int g, int mt, flo
         for (; ku < NKU; ku += kstep) {
             const int rl = 2 * (cpg * a.VW + j) + kh;
             float v = 0.f;
-            if (u < TB && rl < nch && m < mvalid) v = S[m * CKK + rl * a.KK + a.tapmap[c][ta * TB + u]];
+            if (u < TB && rl < nch && m < mvalid) v = S[m * SR + rl * a.KK + a.tapmap[c][ta * TB + u]];
             dst[(int64_t)ku * MTW * LV] = v;
             u += kstep;
             while (u >= a.TBU) { u -= a.TBU; if (++cpg == CPG) { cpg = 0; ++ta; } }
@@ -105,18 +132,25 @@ __device__ __forceinline__ void pack_block(const PackArgs &a, int g, int mt, flo
 }
 
 __global__ __launch_bounds__(256) void conv_pack_kernel(const PackArgs a) {
-    extern __shared__ float S[];                           // [32][CK][KK]
+    extern __shared__ float S[];                           // [32][CK*KK | 1]
     pack_block(a, blockIdx.x, blockIdx.y, S);
 }
 
-// All packing jobs of a training step in ONE launch: block b belongs to the job j with prefix[j] <= b < prefix[j+1].
-__global__ __launch_bounds__(256) void conv_pack_batch_kernel(const PackArgs *jobs, const int *prefix, int njobs) {
+// All packing jobs of a training step in ONE launch: block b belongs to the job j with prefix[j] <= b < prefix[j+1],
+// read from the per-block table when the caller uploaded one (one load instead of a chain of log2(njobs) dependent ones).
+__global__ __launch_bounds__(256) void conv_pack_batch_kernel(const PackArgs *jobs, const int *prefix, const int *block_job,
+                                                              int njobs) {
     extern __shared__ float S[];
-    int lo = 0, hi = njobs;                                // invariant: prefix[lo] <= b < prefix[hi]
     const int b = blockIdx.x;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (prefix[mid] <= b) lo = mid; else hi = mid;
+    int lo = 0;
+    if (block_job) {
+        lo = block_job[b];
+    } else {
+        int hi = njobs;                                    // invariant: prefix[lo] <= b < prefix[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (prefix[mid] <= b) lo = mid; else hi = mid;
+        }
     }
     const PackArgs &a = jobs[lo];
     const int local = b - prefix[lo];
@@ -255,7 +289,9 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     int NST = 3;
     auto lds_bytes = [&](int CK) { return ((size_t)NST * (slab(CK, TAmax) + (size_t)CK * PSRmax) + MB) * 4; };
     // LDS budget: a grid of at most one block per CU may take (nearly) the whole 160 KiB; otherwise leave room for two
-    const int KS0 = nblk < 160 ? (int)(256 / nblk) : 1;     // split-K factor before clamping to the chunk count
+    static const int ks_thr = getenv("DVF_PIPE_KSTHR") ? atoi(getenv("DVF_PIPE_KSTHR")) : 160;       // tuning knobs
+    static const int ks_tgt = getenv("DVF_PIPE_KSTGT") ? atoi(getenv("DVF_PIPE_KSTGT")) : 256;
+    const int KS0 = nblk < ks_thr ? (int)(ks_tgt / nblk) : 1;     // split-K factor before clamping to the chunk count
     const size_t PIPE_LDS_BUDGET = (nblk * KS0 <= 256 ? 150 : 76) * 1024;
     int CK = TBU >= 5 ? 8 : 16;                          // (the 5- and 7-tap kernels are only built for CK <= 8)
     while (CK > 4 && lds_bytes(CK) > PIPE_LDS_BUDGET) CK >>= 1;
@@ -372,7 +408,7 @@ int pipe_pack(PipeOp &op, const float *w, float *packed, int64_t *nfloats, int64
     PipePlan pl;
     int rc = plan_pipe(op.a, op.cls, op.ncls, pl);
     if (rc) return rc;
-    if ((size_t)32 * 2 * pl.CKH * op.KK * sizeof(float) > 64 * 1024) return DVF_ERR_UNSUPPORTED;   // pack kernel's LDS tile
+    if ((size_t)32 * ((2 * pl.CKH * op.KK) | 1) * sizeof(float) > 64 * 1024) return DVF_ERR_UNSUPPORTED;   // pack kernel's LDS tile
     if (nfloats) *nfloats = pl.packed_floats;
     if (wsfloats) *wsfloats = op.covers ? pl.ws_floats : 0;
     if (!w || !packed) return DVF_OK;                       // size query only
@@ -390,7 +426,7 @@ int pipe_pack(PipeOp &op, const float *w, float *packed, int64_t *nfloats, int64
         p.wp_off[c] = a.cls[c].wp_off;
         for (int t = 0; t < op.cls[c].TA * op.cls[c].TB; ++t) p.tapmap[c][t] = (signed char)op.cls[c].tapmap[t];
     }
-    const size_t lds = (size_t)32 * p.CK * p.KK * sizeof(float);
+    const size_t lds = (size_t)32 * ((p.CK * p.KK) | 1) * sizeof(float);
     if (lds > 64 * 1024) return DVF_ERR_UNSUPPORTED;
     const int mtiles = cdiv(a.M, p.MB) * (p.MB >> 5);
     if (job_out) {                                          // export for dvf_conv2d_pack_batch instead of launching

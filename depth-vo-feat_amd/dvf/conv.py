@@ -44,11 +44,13 @@ def _workspace(nfloats, device):
 
 _PACK_REGISTRY = []    # [weakref(weight), desc, segc, kind, cache entry] of every packed copy in use
 _PACK_TABLE = {"n": -1}
+_PACK_SMALL_LDS = 20 * 1024    # bytes: eight 256-thread pack blocks of this size share a CU
 
 
 def repack_all():
-    """Refresh every packed weight copy with ONE launch (called by FlatAdam.step() right after the update, so the
-    convolutions of the next step find their copies current).  The job table is built once per set of layers."""
+    """Refresh every packed weight copy with one launch per tile-size group (called by FlatAdam.step() right after the
+    update, so the convolutions of the next step find their copies current).  The job tables are built once per set of
+    layers."""
     if not L.USE_PIPE or not _PACK_REGISTRY:
         return
     lib = L.lib()
@@ -69,28 +71,41 @@ def repack_all():
                                             L.stream()), "dvf_conv2d_pack")
                 ent[1] = (w.data_ptr(), w._version, L.PACK_EPOCH)
             return
-        blobs, blocks, lds = [], [], ctypes.c_int(4)
+        # jobs are grouped by the LDS tile they need: a launch reserves the maximum of its jobs for every block, and
+        # the few large-kernel layers (7x7, 5x5: ~50 KB) would otherwise hold the 3x3 bulk to three blocks per CU
+        groups = {}
         for r, w in live:
             _, desc, segc, kind, ent = r
             buf = (ctypes.c_char * (L.PACK_JOB_BYTES * len(segc)))()
             nb = (ctypes.c_int * len(segc))()
+            lds = ctypes.c_int(4)
             n = lib.dvf_conv2d_pack_jobs(ctypes.byref(desc), L.int_array(segc), len(segc), kind, L.dev(w), L.dev(ent[0]),
                                          ctypes.cast(buf, ctypes.c_void_p), len(segc), nb, ctypes.byref(lds))
             if n < 0:
                 L.check(n, "dvf_conv2d_pack_jobs")
-            blobs.append(bytes(buf)[: n * L.PACK_JOB_BYTES])
-            blocks += list(nb[:n])
+            g = groups.setdefault(0 if lds.value <= _PACK_SMALL_LDS else 1, {"blobs": [], "blocks": [], "lds": 4})
+            g["blobs"].append(bytes(buf)[: n * L.PACK_JOB_BYTES])
+            g["blocks"] += list(nb[:n])
+            g["lds"] = max(g["lds"], lds.value)
         dev = live[0][1].device
-        prefix = [0]
-        for b in blocks:
-            prefix.append(prefix[-1] + b)
         # (earlier tables stay allocated: a captured graph may still launch with them)
-        t.setdefault("keep", []).append((t.get("jobs"), t.get("prefix")))
-        t["jobs"] = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev)
-        t["prefix"] = torch.tensor(prefix, dtype=torch.int32, device=dev)
-        t["njobs"], t["total"], t["lds"], t["key"] = len(blocks), prefix[-1], lds.value, key
-    L.check(lib.dvf_conv2d_pack_batch(t["jobs"].data_ptr(), t["prefix"].data_ptr(), t["njobs"], t["total"], t["lds"],
-                                      L.stream()), "dvf_conv2d_pack_batch")
+        t.setdefault("keep", []).append(t.get("launches"))
+        t["launches"] = []
+        for _, g in sorted(groups.items()):
+            blocks = g["blocks"]
+            prefix = [0]
+            for b in blocks:
+                prefix.append(prefix[-1] + b)
+            t["launches"].append({
+                "jobs": torch.frombuffer(bytearray(b"".join(g["blobs"])), dtype=torch.uint8).to(dev),
+                "prefix": torch.tensor(prefix, dtype=torch.int32, device=dev),
+                "block_job": torch.repeat_interleave(torch.arange(len(blocks), dtype=torch.int32),
+                                                     torch.tensor(blocks, dtype=torch.int64)).to(dev),
+                "njobs": len(blocks), "total": prefix[-1], "lds": g["lds"]})
+        t["key"] = key
+    for q in t["launches"]:
+        L.check(lib.dvf_conv2d_pack_batch(q["jobs"].data_ptr(), q["prefix"].data_ptr(), q["block_job"].data_ptr(), q["njobs"],
+                                          q["total"], q["lds"], L.stream()), "dvf_conv2d_pack_batch")
     for r, w in live:
         r[4][1] = (w.data_ptr(), w._version, L.PACK_EPOCH)
 

@@ -61,7 +61,7 @@ SIGNATURES = {
     "dvf_conv2d_pack": (c_i, [c_desc, c_ip, c_i, c_i, c_fp, c_fp, c_fp]),
     "dvf_conv2d_ws_floats": (c_i64, [c_desc, c_ip, c_i, c_i]),
     "dvf_conv2d_pack_jobs": (c_i, [c_desc, c_ip, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_ip, c_ip]),
-    "dvf_conv2d_pack_batch": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
+    "dvf_conv2d_pack_batch": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     "dvf_conv2d_fwd_packed": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp]),
     "dvf_conv2d_dgrad_packed": (c_i, [c_desc, c_fp, c_fp, c_fp, c_pp, c_ip, c_i, c_fp, c_i64, c_fp]),
     "dvf_act_bwd": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_fp]),

@@ -169,12 +169,13 @@ int64_t dvf_conv2d_ws_floats(const dvf_conv_desc *d, const int *seg_channels, in
  * memory and their block counts into blocks_out, returning the number of jobs (or a negative DVF_ERR_*).  The caller
  * concatenates the records of all convolutions, uploads them and the exclusive prefix sum of the block counts
  * (njobs + 1 ints) to the device once, and calls dvf_conv2d_pack_batch() after every optimizer step with lds_bytes = the
- * maximum that the pack_jobs calls left in *lds_bytes_out (they only ever raise it). */
+ * maximum that the pack_jobs calls left in *lds_bytes_out (they only ever raise it).  block_job_dev (optional, may be
+ * NULL): total_blocks ints, the job index of every block -- saves each block a binary search through the prefix. */
 #define DVF_PACK_JOB_BYTES 512
 int dvf_conv2d_pack_jobs(const dvf_conv_desc *d, const int *seg_channels, int nseg, int op_kind, const float *w, float *packed,
                          void *jobs_host, int max_jobs, int *blocks_out, int *lds_bytes_out);
-int dvf_conv2d_pack_batch(const void *jobs_dev, const int *block_prefix_dev, int njobs, int total_blocks, int lds_bytes,
-                          void *stream);
+int dvf_conv2d_pack_batch(const void *jobs_dev, const int *block_prefix_dev, const int *block_job_dev, int njobs,
+                          int total_blocks, int lds_bytes, void *stream);
 /* Backward of the fused activation and of the bias in one pass: dpre = dy * act'(y) (y = the forward's
  * output, [N,C,HW]); dbias[c] = sum dpre (zeroed by the call).  dpre or dbias may be NULL. */
 int dvf_act_bwd(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act,
