@@ -73,6 +73,7 @@ class FlatAdam:
         self._ranges = None
         self._reset_pending()
         self.side = torch.cuda.Stream(device=dev) if (wgrad_stream and dev.type == "cuda") else None
+        self._sides = {}         # compute stream -> its weight-gradient stream (the main stream's is self.side)
         self._side_dirty = False
         self._keep = []          # tensors read by side-stream kernels, kept alive until the join
 
@@ -82,16 +83,21 @@ class FlatAdam:
         (or None: run on the current stream).  ``tensors`` are kept alive until ``join_wgrad``."""
         if self.side is None or L.SERIALIZE:
             return None
+        cur = torch.cuda.current_stream()
+        side = self._sides.get(cur.cuda_stream)
+        if side is None:         # one per compute stream: a sub-network on the auxiliary stream gets its own
+            side = self._sides[cur.cuda_stream] = self.side if not self._sides else torch.cuda.Stream(device=cur.device)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.side.wait_event(ev)
+        ev.record(cur)
+        side.wait_event(ev)
         self._keep.extend(t for t in tensors if t is not None)
         self._side_dirty = True
-        return self.side
+        return side
 
     def join_wgrad(self):
         if self._side_dirty:
-            torch.cuda.current_stream().wait_stream(self.side)
+            for side in self._sides.values():
+                torch.cuda.current_stream().wait_stream(side)
             self._side_dirty = False
         self._keep.clear()
 
@@ -125,7 +131,8 @@ class FlatAdam:
         with torch.cuda.stream(self._comm_stream):
             self._comm_stream.wait_event(ev)
             if self._side_dirty:
-                self._comm_stream.wait_stream(self.side)      # the bucket's weight gradients come from the side stream
+                for side in self._sides.values():             # the bucket's weight gradients come from the side streams
+                    self._comm_stream.wait_stream(side)
             for dev, aux in L.AUX_STREAMS.items():            # ... or from a sub-network on the auxiliary stream
                 if dev == self._comm_stream.device:
                     self._comm_stream.wait_stream(aux)
