@@ -232,7 +232,10 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     // runs, loads-only 82 us vs 30 us on the 3x3 128->128 @32x104 layer -- so that is not the way to bring them over)
     // (measured per layer with tools/conv_bench.py: at 17..32 channels the pipelined kernel still wins for the 5x5 / 7x7
     // kernels and for the output-parity classes of stride-2 layers, where a chunk carries many taps per staged byte)
-    if (a.M <= 32 && !ov.on && !(a.M > 16 && (ncls > 1 || Tmax >= 25))) return DVF_ERR_UNSUPPORTED;
+    static const int smallm = getenv("DVF_PIPE_SMALLM") ? atoi(getenv("DVF_PIPE_SMALLM")) : 0;      // tuning knob
+    const bool small_ok = (a.M > 16 && (ncls > 1 || Tmax >= 25)) || ((smallm & 1) && a.M <= 16 && ncls > 1) ||
+                          ((smallm & 2) && a.M <= 16) || ((smallm & 4) && a.M > 16);
+    if (a.M <= 32 && !ov.on && !small_ok) return DVF_ERR_UNSUPPORTED;
     if (ov.on && ov.KS < 0) return DVF_ERR_UNSUPPORTED;      // (tuning: force the gather kernel)
     int maxc = 0;
     for (int s = 0; s < a.nseg; ++s) maxc = a.segC[s] > maxc ? a.segC[s] : maxc;

@@ -1,25 +1,36 @@
 """Build profiles/r01_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) over
 `bench.py --steps 3 --warmup 1 --no-graph --serialize --no-cpu-baseline --no-kernel-timing`.
-usage: traffic.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <steps traced> <out.json>"""
+usage: traffic.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <steps traced | auto> <out.json>
+"auto" counts the optimizer steps in the trace itself (adam_prep_kernel runs once per step, warm-up steps included)."""
 import collections, csv, glob, json, re, sys
 
 GROUPS = ["conv_pipe", "conv_gather", "conv_wgrad", "conv_pack_batch", "splitk_reduce", "act_bwd", "bias_act", "photo_fwd",
           "photo_bwd", "smooth_fwd", "smooth_bwd", "adam", "fillBuffer"]
 
 
+STEPS_SEEN = [0]
+
+
 def collect(d):
     agg = collections.defaultdict(lambda: [0.0, 0])
+    nprep = 0
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
+            if "adam_prep" in r["Kernel_Name"]:
+                nprep += 1
+                continue
             for g in GROUPS:
                 if g in r["Kernel_Name"]:
                     agg[g][0] += float(r["Counter_Value"])
                     agg[g][1] += 1
                     break
+    STEPS_SEEN[0] = nprep
     return agg
 
 
-fetch, write, steps = collect(sys.argv[1]), collect(sys.argv[2]), float(sys.argv[3])
+fetch, write = collect(sys.argv[1]), collect(sys.argv[2])
+steps = float(STEPS_SEEN[0]) if sys.argv[3] == "auto" else float(sys.argv[3])
+print("steps in trace:", STEPS_SEEN[0], "-> normalising by", steps)
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) over `bench.py --steps 3 "
                  "--warmup 1 --no-graph --serialize --no-cpu-baseline --no-kernel-timing` (cfg 2); values are per training step",
        "correction": "FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B "
