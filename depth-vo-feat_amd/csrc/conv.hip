@@ -919,6 +919,11 @@ int dvf_conv2d_fwd(const dvf_conv_desc *d, const float *const *in_segs, const in
         if (!in_segs[0]) return DVF_ERR_INVALID_ARG;
         return dvf_head_fwd(d, in_segs[0], w, bias, out, dvf_stream(stream));
     }
+    if (dvf_head_wide_applicable(d, nseg)) {
+        for (int s = 0; s < nseg; ++s)
+            if (!in_segs[s]) return DVF_ERR_INVALID_ARG;
+        return dvf_head_fwd_segs(d, in_segs, seg_channels, nseg, w, bias, out, dvf_stream(stream));
+    }
     GatherArgs a{};
     for (int s = 0; s < nseg; ++s) {
         if (!in_segs[s]) return DVF_ERR_INVALID_ARG;
@@ -1029,7 +1034,15 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
             a.g_mstride = (int64_t)d->C_out * KK; a.g_mbase = off; a.g_cbase = 0;
         }
         const int MT = a.M > 32 ? 2 : 1;
-        const int NTW = KK >= 25 ? 2 : 1;
+        // column tiles per wave: two when the kernel is large, or when that lets fewer channel chunks (each of which
+        // re-reads the whole P tensor) cover the segment
+        static const int ntw_mode = getenv("DVF_WG_NTW2") ? atoi(getenv("DVF_WG_NTW2")) : 0;     // tuning knob
+        int NTW = KK >= 25 ? 2 : 1;
+        if (NTW == 1 && KK <= 128) {
+            const int n1 = cdiv(a.Cq, 128 / KK), n2 = cdiv(a.Cq, 256 / KK);
+            if ((ntw_mode == 1 && n2 == 1 && n1 > 1) || (ntw_mode == 2 && n2 < n1) || (ntw_mode == 3 && n2 < n1 && a.Cq * KK <= 1024))
+                NTW = 2;
+        }
         int CK = (128 * NTW) / KK;
         if (CK < 1) CK = 1;
         if (CK > a.Cq) CK = a.Cq;

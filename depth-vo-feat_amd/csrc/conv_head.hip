@@ -32,8 +32,13 @@ __device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__
 // computes the dgrad of a narrow input segment (m = segment channel, c = output channel of the convolution, taps flipped).
 // Tile 64 x 8 pixels, two rows per thread; the per-thread staging offsets are channel-invariant.
 constexpr int FT_H = 8, FP_H = FT_H + 2, FP_N = FP_H * HP_W, F_LD = (FP_N + 255) / 256;
+struct HeadSegs {                            // the input: a virtual concat of up to DVF_MAX_SEGS tensors
+    const float *p[DVF_MAX_SEGS];
+    int c[DVF_MAX_SEGS];
+    int n;
+};
 template <int MO>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ in, const float *__restrict__ w,
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const float *__restrict__ w,
                                                        const float *__restrict__ bias, float *__restrict__ out, int C, int H,
                                                        int W, int tilesX, int act, float alpha, float beta, int ws_m, int ws_c,
                                                        int flip) {
@@ -59,17 +64,23 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
     for (int m = 0; m < MO; ++m) acc[0][m] = acc[1][m] = bias ? bias[m] : 0.f;
     // the loads of chunk c0 + HCK are issued before the FMAs of chunk c0 (registers), so their latency overlaps them
     float stg[HCK][F_LD];
-    auto issue = [&](int c0) {
-        const int nch = min(HCK, C - c0);
-        const float *src = in + ((int64_t)n * C + c0) * plane;
+    static_assert(DVF_MAX_SEGS == 3, "segment select below");
+    auto seg_ptr = [&](int sg) { return sg == 0 ? in.p[0] : sg == 1 ? in.p[1] : in.p[2]; };
+    auto seg_ch = [&](int sg) { return sg == 0 ? in.c[0] : sg == 1 ? in.c[1] : in.c[2]; };
+    auto issue = [&](int sg, int cs) {       // chunk = up to HCK channels of ONE segment, starting at its channel cs
+        const int sc = seg_ch(sg), nch = min(HCK, sc - cs);
+        const float *src = seg_ptr(sg) + ((int64_t)n * sc + cs) * plane;
 #pragma unroll
         for (int ch = 0; ch < HCK; ++ch)
 #pragma unroll
             for (int i = 0; i < F_LD; ++i) stg[ch][i] = (ch < nch && soff[i] >= 0) ? src[ch * plane + soff[i]] : 0.f;
     };
-    issue(0);
-    for (int c0 = 0; c0 < C; c0 += HCK) {
-        const int nch = min(HCK, C - c0);
+    issue(0, 0);
+    int sg = 0, cs = 0, cg = 0;              // current chunk: segment, channel inside it, channel of the concat
+    while (sg < in.n) {
+        const int nch = min(HCK, seg_ch(sg) - cs);
+        int sg2 = sg, cs2 = cs + HCK;
+        if (cs2 >= seg_ch(sg)) { ++sg2; cs2 = 0; }
         __syncthreads();
 #pragma unroll
         for (int ch = 0; ch < HCK; ++ch)
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
                 if (e < FP_N) tile[ch * FP_N + e] = stg[ch][i];
             }
         __syncthreads();
-        if (c0 + HCK < C) issue(c0 + HCK);
+        if (sg2 < in.n) issue(sg2, cs2);
         for (int ch = 0; ch < nch; ++ch) {
             const float *t = tile + ch * FP_N + ly * HP_W + lx;
             float v[4][3];
@@ -89,7 +100,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
                 for (int b = 0; b < 3; ++b) v[a][b] = t[a * HP_W + b];
 #pragma unroll
             for (int m = 0; m < MO; ++m) {
-                const float *wm = wsh + (m * C + c0 + ch) * 9;             // LDS broadcast reads
+                const float *wm = wsh + (m * C + cg + ch) * 9;             // LDS broadcast reads
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const float wk = wm[k];
@@ -98,6 +109,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
                 }
             }
         }
+        cg += nch; sg = sg2; cs = cs2;
     }
     const int x = x0 + lx;
 #pragma unroll
@@ -218,11 +230,38 @@ bool dvf_head_applicable(const dvf_conv_desc *d, int nseg) {
         default: return DVF_ERR_UNSUPPORTED;     \
     }
 
+#define HEAD_FWD_DISPATCH(MOV, CALL)             \
+    switch (MOV) {                               \
+        case 1: { constexpr int MO = 1; CALL; } break; \
+        case 2: { constexpr int MO = 2; CALL; } break; \
+        case 3: { constexpr int MO = 3; CALL; } break; \
+        case 4: { constexpr int MO = 4; CALL; } break; \
+        case 16: { constexpr int MO = 16; CALL; } break; \
+        default: return DVF_ERR_UNSUPPORTED;     \
+    }
+
 int dvf_head_fwd(const dvf_conv_desc *d, const float *in, const float *w, const float *bias, float *out, hipStream_t st) {
+    const int one = d->C_in;
+    return dvf_head_fwd_segs(d, &in, &one, 1, w, bias, out, st);
+}
+
+// Thin full-resolution layers (iconv1: 16+1 -> 16 channels at the input resolution, DispNetS.py:126): a 32-row MFMA tile
+// is half padding and the reduction (153 deep) too short to amortise a tile's prologue, so the direct kernel is ~2x faster.
+bool dvf_head_wide_applicable(const dvf_conv_desc *d, int nseg) {
+    return nseg >= 1 && nseg <= DVF_MAX_SEGS && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
+           d->C_out == 16 && d->C_in <= 24 && d->H_out == d->H_in && d->W_out == d->W_in &&
+           (int64_t)d->H_in * d->W_in >= 64 * 64 && getenv("DVF_NO_HEAD") == nullptr && getenv("DVF_NO_WIDE_HEAD") == nullptr;
+}
+
+int dvf_head_fwd_segs(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg, const float *w,
+                      const float *bias, float *out, hipStream_t st) {
     const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, FT_H);
     const dim3 grid(tilesX * tilesY, d->N);
-    HEAD_DISPATCH(d->C_out, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_in * 9 * 4, st>>>(
-                                 in, w, bias, out, d->C_in, d->H_in, d->W_in, tilesX, d->act, d->alpha, d->beta, d->C_in * 9, 9, 0)));
+    HeadSegs in{};
+    for (int s = 0; s < DVF_MAX_SEGS; ++s) { in.p[s] = s < nseg ? in_segs[s] : in_segs[0]; in.c[s] = s < nseg ? seg_channels[s] : 0; }
+    in.n = nseg;
+    HEAD_FWD_DISPATCH(d->C_out, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_in * 9 * 4, st>>>(
+                                    in, w, bias, out, d->C_in, d->H_in, d->W_in, tilesX, d->act, d->alpha, d->beta, d->C_in * 9, 9, 0)));
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }
@@ -231,9 +270,11 @@ int dvf_head_fwd(const dvf_conv_desc *d, const float *in, const float *w, const 
 //   din[n][ci][y][x] = sum_co sum_taps w[co][seg_off+ci][ta][tb] * dpre[n][co][y-ta+1][x-tb+1]
 // = the head forward over dpre with transposed, tap-flipped weights.
 bool dvf_head_seg_dgrad_applicable(const dvf_conv_desc *d, int segc) {
-    return !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && segc >= 1 && segc <= 4 &&
-           d->H_out == d->H_in && d->W_out == d->W_in && d->C_out >= 4 && d->C_out * segc <= 1024 &&
-           getenv("DVF_NO_HEAD") == nullptr;
+    const bool narrow = segc >= 1 && segc <= 4 && d->C_out >= 4 && d->C_out * segc <= 1024;
+    const bool wide = segc == 16 && d->C_out <= 24 && (int64_t)d->H_in * d->W_in >= 64 * 64 &&     // see dvf_head_wide_applicable
+                      getenv("DVF_NO_WIDE_HEAD") == nullptr;
+    return !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && (narrow || wide) &&
+           d->H_out == d->H_in && d->W_out == d->W_in && getenv("DVF_NO_HEAD") == nullptr;
 }
 
 int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int seg_off, int segc,
@@ -241,8 +282,11 @@ int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w
     const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, FT_H);
     const dim3 grid(tilesX * tilesY, d->N);
     const float *wseg = w + (int64_t)seg_off * 9;
-    HEAD_DISPATCH(segc, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_out * 9 * 4, st>>>(
-                             dpre, wseg, nullptr, din, d->C_out, d->H_in, d->W_in, tilesX, DVF_ACT_NONE, 1.f, 0.f, 9, d->C_in * 9, 1)));
+    HeadSegs in{};
+    for (int s = 0; s < DVF_MAX_SEGS; ++s) { in.p[s] = dpre; in.c[s] = s == 0 ? d->C_out : 0; }
+    in.n = 1;
+    HEAD_FWD_DISPATCH(segc, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_out * 9 * 4, st>>>(
+                                in, wseg, nullptr, din, d->C_out, d->H_in, d->W_in, tilesX, DVF_ACT_NONE, 1.f, 0.f, 9, d->C_in * 9, 1)));
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }

@@ -43,6 +43,10 @@ CASES = [
     ("t4x4_s2", [64], 32, 4, 2, 1, 0, True, 1, (2, 8, 13), None),
     ("t4x4_s2_crop", [32], 16, 4, 2, 1, 0, True, 1, (1, 16, 26), (31, 51)),
     ("c3x3_wide", [32], 32, 3, 1, 1, 0, False, 1, (1, 40, 208), None),
+    # thin full-resolution layers (iconv1): direct kernel, forward over the virtual concat + dgrad of the 16-channel segment
+    ("thin16_concat2_ragged", [16, 1], 16, 3, 1, 1, 0, False, 1, (2, 70, 75), None),
+    ("thin16_concat3", [8, 13, 3], 16, 3, 1, 1, 0, False, 1, (1, 64, 66), None),
+    ("thin16_single_noact", [16], 16, 3, 1, 1, 0, False, 0, (1, 65, 64), None),
 ]
 
 
