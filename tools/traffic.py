@@ -2,7 +2,7 @@
 `bench.py --steps 3 --warmup 1 --no-graph --serialize --no-cpu-baseline --no-kernel-timing`.
 usage: traffic.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <steps traced | auto> <out.json>
 "auto" counts the optimizer steps in the trace itself (adam_prep_kernel runs once per step, warm-up steps included)."""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
 
 GROUPS = ["conv_pipe", "conv_gather", "conv_wgrad", "conv_pack_batch", "splitk_reduce", "act_bwd", "bias_act", "photo_fwd",
           "photo_bwd", "smooth_fwd", "smooth_bwd", "adam", "fillBuffer"]
@@ -14,7 +14,8 @@ STEPS_SEEN = [0]
 def collect(d):
     agg = collections.defaultdict(lambda: [0.0, 0])
     nprep = 0
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:                     # gpurun merges every run's files into the same directory: newest only
         for r in csv.DictReader(open(f)):
             if "adam_prep" in r["Kernel_Name"]:
                 nprep += 1
