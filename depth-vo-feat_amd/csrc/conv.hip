@@ -1057,13 +1057,16 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
         a.RS = (a.S == 2) ? 2 * a.PWH : a.PWq;
         a.PS = a.PHq * a.RS;
         a.COTP = 32 * MT + 1;
-        // keep the block's LDS (Q patch + transposed P tile) under 48 KiB: 3 blocks per CU
-        static const size_t wg_lds_cap = (getenv("DVF_WG_LDS_KB") ? atoi(getenv("DVF_WG_LDS_KB")) : 52) * 1024;   // 3 blocks per CU (swept 36..60 KB on cfg 2)
+        // the block's LDS (Q patch + transposed P tile) may take the whole 64 KiB a block can address with immediate
+        // offsets: two blocks per CU, but as many patch channels per block as fit -- every channel chunk re-reads the
+        // whole P tensor, and fewer chunks beat a third resident block (swept 36..64 KB on cfg 2: 44 KB 9.02 ms/step,
+        // 52 KB 8.57, 56 KB 8.47, 64 KB 8.43)
+        static const size_t wg_lds_cap = (getenv("DVF_WG_LDS_KB") ? atoi(getenv("DVF_WG_LDS_KB")) : 64) * 1024;
         while (CK > 1 && ((size_t)CK * a.PS + (size_t)a.BH * WG_BW * a.COTP) * 4 > wg_lds_cap) --CK;
         a.CK = CK;
         const int mtiles = cdiv(a.M, 32 * MT), cchunks = cdiv(a.Cq, CK);
         const int ntiles = a.N * a.tilesX * a.tilesY;
-        static const int wg_target = getenv("DVF_WG_BLOCKS") ? atoi(getenv("DVF_WG_BLOCKS")) : 768;    // tuning knob (swept on cfg 2: 512..2048)
+        static const int wg_target = getenv("DVF_WG_BLOCKS") ? atoi(getenv("DVF_WG_BLOCKS")) : 512;    // one round of 2 blocks per CU (swept on cfg 2: 512..2048)
         int psplit = wg_target / (mtiles * cchunks);
         if (psplit < 1) psplit = 1;
         if (psplit > ntiles) psplit = ntiles;
