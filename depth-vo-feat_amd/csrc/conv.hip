@@ -1073,7 +1073,20 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
         if (psplit > 65535 || cchunks > 65535) return DVF_ERR_UNSUPPORTED;
         a.PSPLIT = psplit;
         const size_t lds = ((size_t)CK * a.PS + (size_t)a.BH * WG_BW * a.COTP) * 4;
-        if (lds > 64 * 1024) return DVF_ERR_UNSUPPORTED;
+        if (lds > 80 * 1024) return DVF_ERR_UNSUPPORTED;
+        {   // more than the default 64 KiB of dynamic LDS needs the per-function opt-in (once per process)
+            static const bool raised = [] {
+                const void *fns[] = {(const void *)&conv_wgrad_kernel<2, 2, true>,  (const void *)&conv_wgrad_kernel<2, 1, true>,
+                                     (const void *)&conv_wgrad_kernel<1, 2, true>,  (const void *)&conv_wgrad_kernel<1, 1, true>,
+                                     (const void *)&conv_wgrad_kernel<2, 2, false>, (const void *)&conv_wgrad_kernel<2, 1, false>,
+                                     (const void *)&conv_wgrad_kernel<1, 2, false>, (const void *)&conv_wgrad_kernel<1, 1, false>};
+                bool ok = true;
+                for (const void *f : fns)
+                    ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+                return ok;
+            }();
+            if (!raised && lds > 64 * 1024) return DVF_ERR_UNSUPPORTED;
+        }
         if ((int64_t)a.N * a.PCtot * a.GH * a.GW * 4 >= ((int64_t)1 << 31) - 16 ||
             (int64_t)a.N * a.QCtot * a.QH * a.QW * 4 >= ((int64_t)1 << 31) - 16)
             return DVF_ERR_UNSUPPORTED;             // 32-bit byte offsets inside the kernel
