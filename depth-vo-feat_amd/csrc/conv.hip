@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
         // ---- stage the input patch.  Row bookkeeping is scalar and incremental (no divisions); everything that
         // depends on the lane (column offset, column validity, LDS column) was computed once before the chunk loop.
         // 8 independent buffer loads are issued before the 8 LDS stores.
-        if (!(a.dbg & 1)) {
+        if (!DVF_DBG(a, 1)) {
             const __amdgpu_buffer_rsrc_t rs_in = tensor_rsrc(a.in[seg]);
             const unsigned cb = (unsigned)((n * a.segC[seg] + c0) * a.IH * a.IW) << 2;      // chunk base, bytes
             int ci = 0, r = wave;                              // this wave's next row (ci, r); rows advance by 4
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
         }
         // ---- stage the weight slab wl[(t*CK + r)*COTP + m]: lanes walk the contiguous run of the stored tensor
         // (coalesced), wdec[] maps a run position to its LDS slot; row bases are scalar 32-bit offsets.
-        if (!(a.dbg & 2)) {
+        if (!DVF_DBG(a, 2)) {
             const int r0 = r_seg + c0;                        // reduction index of the chunk's first channel
             if (a.w_mode == 0) {
                 const int nE = CK * a.KK;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
         }
         __syncthreads();
         // ---- MFMA: per tap, all CKH channel pairs; the next tap's fragments are fetched before this tap's MFMAs
-        if (!(a.dbg & 4)) {
+        if (!DVF_DBG(a, 4)) {
             float af[2][CKH][MT], bf[2][CKH][NT];
             auto load = [&](auto bufc, int t) {
                 constexpr int buf = decltype(bufc)::value;
@@ -745,7 +745,7 @@ int plan_gather(GatherArgs &a, const ClassSpec *cls, int ncls, GatherPlan &pl) {
         return ((size_t)CK * a.PSmax + (size_t)Tmax * CK * COTP + WD + Tmax + 64) * 4;
     };
     int CK = 16;
-    static const size_t g_lds_cap = (getenv("DVF_G_LDS_KB") ? atoi(getenv("DVF_G_LDS_KB")) : 40) * 1024;     // tuning knob
+    static const size_t g_lds_cap = (dvf_tune("DVF_G_LDS_KB") ? atoi(dvf_tune("DVF_G_LDS_KB")) : 40) * 1024;     // tuning knob
     while (CK > 2 && lds_bytes(CK) > g_lds_cap) CK >>= 1;
     while (CK > 2 && CK / 2 >= maxc) CK >>= 1;
     if (lds_bytes(CK) > 64 * 1024) return DVF_ERR_UNSUPPORTED;
@@ -758,7 +758,7 @@ int plan_gather(GatherArgs &a, const ClassSpec *cls, int ncls, GatherPlan &pl) {
     if (KS < 1) KS = 1;
     if ((int64_t)a.N * KS * ncls > 65535) return DVF_ERR_UNSUPPORTED;
     a.KS = KS;
-    if (const char *e = getenv("DVF_DBG")) a.dbg = atoi(e);     // ablation switches for tools/conv_bench.py only
+    if (const char *e = dvf_tune("DVF_DBG")) a.dbg = atoi(e);     // ablation switches for tools/conv_bench.py only
     // the kernels address each tensor with 32-bit byte offsets
     for (int s2 = 0; s2 < a.nseg; ++s2)
         if ((int64_t)a.N * a.segC[s2] * a.IH * a.IW * 4 >= ((int64_t)1 << 31) - 16) return DVF_ERR_UNSUPPORTED;
@@ -798,6 +798,7 @@ int run_classes(const GatherArgs &base, const ClassSpec *cls, int ncls, bool cov
     else if (pl.NT == 2) rc = launch_gather_ck<1, 2>(a, pl, st);
     else rc = launch_gather_ck<1, 1>(a, pl, st);
     if (rc) return rc;
+    dvf_plan_note(DVF_K_GATHER, pl.MT, pl.NT, 1, 2 * pl.CKH, 0, a.KS, 1, 1, 256, (int)pl.lds, (split ? 1 : 0) | (a.ncls << 4));
     if (split && (a.bias || a.act != DVF_ACT_NONE)) {
         const int64_t nb = (total + 255) / 256;
         bias_act_kernel<<<(int)(nb > 2048 ? 2048 : nb), 256, 0, st>>>(a.out, a.bias, a.M, HW, total, a.act, a.alpha,
@@ -910,6 +911,7 @@ extern "C" {
 
 int dvf_conv2d_fwd(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
                    const float *w, const float *bias, float *out, void *stream) {
+    dvf_plan_reset();
     int rc = check_desc(d);
     if (rc) return rc;
     rc = check_segs(d, seg_channels, nseg);
@@ -982,6 +984,7 @@ extern "C" {
 
 int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *const *din_segs,
                      const int *seg_channels, int nseg, void *stream) {
+    dvf_plan_reset();
     int rc = check_desc(d);
     if (rc) return rc;
     rc = check_segs(d, seg_channels, nseg);
@@ -1002,6 +1005,7 @@ int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, 
 
 int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
                      const float *dpre, float *dw, int accumulate, void *stream) {
+    dvf_plan_reset();
     int rc = check_desc(d);
     if (rc) return rc;
     rc = check_segs(d, seg_channels, nseg);
@@ -1036,7 +1040,7 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
         const int MT = a.M > 32 ? 2 : 1;
         // column tiles per wave: two when the kernel is large, or when that lets fewer channel chunks (each of which
         // re-reads the whole P tensor) cover the segment
-        static const int ntw_mode = getenv("DVF_WG_NTW2") ? atoi(getenv("DVF_WG_NTW2")) : 0;     // tuning knob
+        static const int ntw_mode = dvf_tune("DVF_WG_NTW2") ? atoi(dvf_tune("DVF_WG_NTW2")) : 0;     // tuning knob
         int NTW = KK >= 25 ? 2 : 1;
         if (NTW == 1 && KK <= 128) {
             const int n1 = cdiv(a.Cq, 128 / KK), n2 = cdiv(a.Cq, 256 / KK);
@@ -1061,12 +1065,12 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
         // offsets: two blocks per CU, but as many patch channels per block as fit -- every channel chunk re-reads the
         // whole P tensor, and fewer chunks beat a third resident block (swept 36..64 KB on cfg 2: 44 KB 9.02 ms/step,
         // 52 KB 8.57, 56 KB 8.47, 64 KB 8.43)
-        static const size_t wg_lds_cap = (getenv("DVF_WG_LDS_KB") ? atoi(getenv("DVF_WG_LDS_KB")) : 64) * 1024;
+        static const size_t wg_lds_cap = (dvf_tune("DVF_WG_LDS_KB") ? atoi(dvf_tune("DVF_WG_LDS_KB")) : 64) * 1024;
         while (CK > 1 && ((size_t)CK * a.PS + (size_t)a.BH * WG_BW * a.COTP) * 4 > wg_lds_cap) --CK;
         a.CK = CK;
         const int mtiles = cdiv(a.M, 32 * MT), cchunks = cdiv(a.Cq, CK);
         const int ntiles = a.N * a.tilesX * a.tilesY;
-        static const int wg_target = getenv("DVF_WG_BLOCKS") ? atoi(getenv("DVF_WG_BLOCKS")) : 512;    // one round of 2 blocks per CU (swept on cfg 2: 512..2048)
+        static const int wg_target = dvf_tune("DVF_WG_BLOCKS") ? atoi(dvf_tune("DVF_WG_BLOCKS")) : 512;    // one round of 2 blocks per CU (swept on cfg 2: 512..2048)
         int psplit = wg_target / (mtiles * cchunks);
         if (psplit < 1) psplit = 1;
         if (psplit > ntiles) psplit = ntiles;
@@ -1092,10 +1096,11 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
             return DVF_ERR_UNSUPPORTED;             // 32-bit byte offsets inside the kernel
         const dim3 grid(mtiles, cchunks, psplit);
         // register prefetch of the next tile when a wave's share of the Q patch fits the register budget (one pass)
-        static const bool no_pf = getenv("DVF_WG_NOPF") != nullptr;
+        static const bool no_pf = dvf_tune("DVF_WG_NOPF") != nullptr;
         const bool pf = !no_pf && a.PWq <= 64 && cdiv(CK * a.PHq, 4) <= 24 && 8 * MT * (a.BH >> 1) <= 16 * MT;
-        static const bool no_vp = getenv("DVF_WG_NOVP") != nullptr;
+        static const bool no_vp = dvf_tune("DVF_WG_NOVP") != nullptr;
         a.vp = (pf && !no_vp && a.GW % 4 == 0 && (reinterpret_cast<uintptr_t>(a.P) & 15) == 0) ? 1 : 0;
+        dvf_plan_note(DVF_K_WGRAD, MT, NTW, pf ? 1 : 0, CK, a.BH, psplit, a.vp, a.S, 256, (int)lds, KK);
         if (pf) {
             if (MT == 2 && NTW == 2) conv_wgrad_kernel<2, 2, true><<<grid, 256, lds, st>>>(a);
             else if (MT == 2) conv_wgrad_kernel<2, 1, true><<<grid, 256, lds, st>>>(a);
@@ -1213,6 +1218,7 @@ int dvf_conv2d_pack(const dvf_conv_desc *d, const int *seg_channels, int nseg, i
 
 int dvf_conv2d_fwd_packed(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
                           const float *packed, const float *bias, float *out, float *ws, int64_t ws_floats, void *stream) {
+    dvf_plan_reset();
     int rc = check_desc(d);
     if (rc) return rc;
     rc = check_segs(d, seg_channels, nseg);
@@ -1229,6 +1235,7 @@ int dvf_conv2d_fwd_packed(const dvf_conv_desc *d, const float *const *in_segs, c
 int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const float *packed, const float *w,
                             float *const *din_segs, const int *seg_channels, int nseg, float *ws, int64_t ws_floats,
                             void *stream) {
+    dvf_plan_reset();
     int rc = check_desc(d);
     if (rc) return rc;
     rc = check_segs(d, seg_channels, nseg);

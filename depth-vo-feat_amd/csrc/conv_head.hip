@@ -218,7 +218,7 @@ inline int cdivh(int a, int b) { return (a + b - 1) / b; }
 bool dvf_head_applicable(const dvf_conv_desc *d, int nseg) {
     return nseg == 1 && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->C_out >= 1 &&
            d->C_out <= 4 && d->H_out == d->H_in && d->W_out == d->W_in && d->C_in >= 4 && d->C_in * d->C_out <= 1024 &&
-           getenv("DVF_NO_HEAD") == nullptr;
+           dvf_tune("DVF_NO_HEAD") == nullptr;
 }
 
 #define HEAD_DISPATCH(MOV, CALL)                 \
@@ -250,7 +250,7 @@ int dvf_head_fwd(const dvf_conv_desc *d, const float *in, const float *w, const 
 bool dvf_head_wide_applicable(const dvf_conv_desc *d, int nseg) {
     return nseg >= 1 && nseg <= DVF_MAX_SEGS && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
            d->C_out == 16 && d->C_in <= 24 && d->H_out == d->H_in && d->W_out == d->W_in &&
-           (int64_t)d->H_in * d->W_in >= 64 * 64 && getenv("DVF_NO_HEAD") == nullptr && getenv("DVF_NO_WIDE_HEAD") == nullptr;
+           (int64_t)d->H_in * d->W_in >= 64 * 64 && dvf_tune("DVF_NO_HEAD") == nullptr && dvf_tune("DVF_NO_WIDE_HEAD") == nullptr;
 }
 
 int dvf_head_fwd_segs(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg, const float *w,
@@ -263,6 +263,7 @@ int dvf_head_fwd_segs(const dvf_conv_desc *d, const float *const *in_segs, const
     HEAD_FWD_DISPATCH(d->C_out, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_in * 9 * 4, st>>>(
                                     in, w, bias, out, d->C_in, d->H_in, d->W_in, tilesX, d->act, d->alpha, d->beta, d->C_in * 9, 9, 0)));
     DVF_LAUNCH_CHECK();
+    dvf_plan_note(DVF_K_HEAD_FWD, d->C_out, nseg);
     return DVF_OK;
 }
 
@@ -272,9 +273,9 @@ int dvf_head_fwd_segs(const dvf_conv_desc *d, const float *const *in_segs, const
 bool dvf_head_seg_dgrad_applicable(const dvf_conv_desc *d, int segc) {
     const bool narrow = segc >= 1 && segc <= 4 && d->C_out >= 4 && d->C_out * segc <= 1024;
     const bool wide = segc == 16 && d->C_out <= 24 && (int64_t)d->H_in * d->W_in >= 64 * 64 &&     // see dvf_head_wide_applicable
-                      getenv("DVF_NO_WIDE_HEAD") == nullptr;
+                      dvf_tune("DVF_NO_WIDE_HEAD") == nullptr;
     return !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && (narrow || wide) &&
-           d->H_out == d->H_in && d->W_out == d->W_in && getenv("DVF_NO_HEAD") == nullptr;
+           d->H_out == d->H_in && d->W_out == d->W_in && dvf_tune("DVF_NO_HEAD") == nullptr;
 }
 
 int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int seg_off, int segc,
@@ -288,6 +289,7 @@ int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w
     HEAD_FWD_DISPATCH(segc, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_out * 9 * 4, st>>>(
                                 in, wseg, nullptr, din, d->C_out, d->H_in, d->W_in, tilesX, DVF_ACT_NONE, 1.f, 0.f, 9, d->C_in * 9, 1)));
     DVF_LAUNCH_CHECK();
+    dvf_plan_note(DVF_K_HEAD_SEG_DGRAD, segc);
     return DVF_OK;
 }
 
@@ -296,6 +298,7 @@ int dvf_head_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, fl
     const dim3 grid(tilesX * tilesY, d->N);
     HEAD_DISPATCH(d->C_out, (head_dgrad_kernel<MO><<<grid, 256, 0, st>>>(dpre, w, din, d->C_in, d->H_in, d->W_in, tilesX)));
     DVF_LAUNCH_CHECK();
+    dvf_plan_note(DVF_K_HEAD_DGRAD, d->C_out);
     return DVF_OK;
 }
 
@@ -311,5 +314,6 @@ int dvf_head_wgrad(const dvf_conv_desc *d, const float *in, const float *dpre, f
     HEAD_DISPATCH(d->C_out, (head_wgrad_kernel<MO><<<grid, 256, 0, st>>>(in, dpre, dw, d->N, d->C_in, d->H_in, d->W_in, tilesX,
                                                                         tilesY)));
     DVF_LAUNCH_CHECK();
+    dvf_plan_note(DVF_K_HEAD_WGRAD, d->C_out);
     return DVF_OK;
 }

@@ -181,13 +181,13 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
             }
             float *wl = smem + st * stage_floats;
             float *patch = wl + a.SLmax;
-            if (!(a.dbg & 2)) {
+            if (!DVF_DBG(a, 2)) {
                 const unsigned slab = (c.wp_off + (unsigned)(mb * a.NCH + g) * (unsigned)c.SL) << 2;
                 for (int p = half; p < NWP; p += nhalf)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)(wl + (p << 8)), 16, (unsigned)lane << 4,
                                                              slab + ((unsigned)p << 10), 0, 0);
             }
-            if (!(a.dbg & 1)) {
+            if (!DVF_DBG(a, 1)) {
                 const int segc = a.segC[iseg];
                 const int c0 = (g - iseg_first) * CK;
                 const int nch = min(CK, segc - c0);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
                 }
             }
         };
-        if (a.dbg & 8) return;
+        if DVF_DBG(a, 8) return;
         // Chunk x (counted from g_begin) belongs to producer x & 1 and lives in stage x % NST; it is issued NST-1 chunks
         // ahead.  A producer never has more than one chunk in flight, so "my chunk has landed" is a plain vmcnt(0).
         const int D = a.NST - 1, nchunks = g_end - g_begin;
@@ -364,11 +364,11 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
         }
     };
 
-    if (!(a.dbg & 8)) {
+    if (!DVF_DBG(a, 8)) {
         int st = 0;
         for (int g = g_begin; g < g_end; ++g) {
             __syncthreads();          // chunk g has landed (its producer waited for it) and chunk g-1 is fully consumed
-            if (!(a.dbg & 4)) {
+            if (!DVF_DBG(a, 4)) {
                 if (a.IS == 2) consume(st, std::integral_constant<int, 2>{});
                 else consume(st, std::integral_constant<int, 1>{});
             }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
     }
 
     // ---- epilogue: D[row = channel][col = pixel]; lanes 0-31 / 32-63 hold channel rows +0 / +4
-    if (a.dbg & 16) return;
+    if DVF_DBG(a, 16) return;
     const int m0 = mb * (32 * MTW) + wm * (32 * MT);
     float *outp = a.out + (a.out_mode == 2 ? (int64_t)ks * a.ws_slice : 0);
     const int64_t HW = (int64_t)a.OH * a.OW;

@@ -179,7 +179,7 @@ struct PipePlan {
 struct PipeOverride { int on, MT, NT, WM, CK, KS, BN, NST; };
 inline PipeOverride pipe_override() {
     PipeOverride o{0, 0, 0, 0, 0, 0, 0, 0};
-    if (const char *e = getenv("DVF_PIPE_PLAN"))         // "MT,NT,WM,CK,KS,BN,NST" (0 = automatic) -- tuning tool only
+    if (const char *e = dvf_tune("DVF_PIPE_PLAN"))         // "MT,NT,WM,CK,KS,BN,NST" (0 = automatic) -- tuning tool only
         if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &o.MT, &o.NT, &o.WM, &o.CK, &o.KS, &o.BN, &o.NST) >= 1) o.on = 1;
     return o;
 }
@@ -232,7 +232,7 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     // runs, loads-only 82 us vs 30 us on the 3x3 128->128 @32x104 layer -- so that is not the way to bring them over)
     // (measured per layer with tools/conv_bench.py: at 17..32 channels the pipelined kernel still wins for the 5x5 / 7x7
     // kernels and for the output-parity classes of stride-2 layers, where a chunk carries many taps per staged byte)
-    static const int smallm = getenv("DVF_PIPE_SMALLM") ? atoi(getenv("DVF_PIPE_SMALLM")) : 0;      // tuning knob
+    static const int smallm = dvf_tune("DVF_PIPE_SMALLM") ? atoi(dvf_tune("DVF_PIPE_SMALLM")) : 0;      // tuning knob
     const bool small_ok = (a.M > 16 && (ncls > 1 || Tmax >= 25)) || ((smallm & 1) && a.M <= 16 && ncls > 1) ||
                           ((smallm & 2) && a.M <= 16) || ((smallm & 4) && a.M > 16);
     if (a.M <= 32 && !ov.on && !small_ok) return DVF_ERR_UNSUPPORTED;
@@ -292,8 +292,8 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     int NST = 3;
     auto lds_bytes = [&](int CK) { return ((size_t)NST * (slab(CK, TAmax) + (size_t)CK * PSRmax) + MB) * 4; };
     // LDS budget: a grid of at most one block per CU may take (nearly) the whole 160 KiB; otherwise leave room for two
-    static const int ks_thr = getenv("DVF_PIPE_KSTHR") ? atoi(getenv("DVF_PIPE_KSTHR")) : 160;       // tuning knobs
-    static const int ks_tgt = getenv("DVF_PIPE_KSTGT") ? atoi(getenv("DVF_PIPE_KSTGT")) : 256;
+    static const int ks_thr = dvf_tune("DVF_PIPE_KSTHR") ? atoi(dvf_tune("DVF_PIPE_KSTHR")) : 160;       // tuning knobs
+    static const int ks_tgt = dvf_tune("DVF_PIPE_KSTGT") ? atoi(dvf_tune("DVF_PIPE_KSTGT")) : 256;
     const int KS0 = nblk < ks_thr ? (int)(ks_tgt / nblk) : 1;     // split-K factor before clamping to the chunk count
     const size_t PIPE_LDS_BUDGET = (nblk * KS0 <= 256 ? 150 : 76) * 1024;
     int CK = TBU >= 5 ? 8 : 16;                          // (the 5- and 7-tap kernels are only built for CK <= 8)
@@ -341,7 +341,7 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     // a block that has a CU to itself (by LDS size or by grid size) gets four producer waves, one per SIMD
     {
         const int64_t nblocks_total = (int64_t)pl.grid.x * pl.grid.y * pl.grid.z;
-        static const bool no4p = getenv("DVF_PIPE_NO4P") != nullptr;
+        static const bool no4p = dvf_tune("DVF_PIPE_NO4P") != nullptr;
         // (32-channel MFMA waves need <= 128 VGPRs: two 8-wave blocks still fit a CU)
         pl.threads = (!no4p && (pl.lds > 76 * 1024 || nblocks_total <= 256 || MT == 1)) ? dvfp::PIPE_THREADS_4P : dvfp::PIPE_THREADS;
     }
@@ -387,8 +387,9 @@ int pipe_run(PipeOp &op, const float *packed, float *ws, int64_t ws_floats, hipS
     if (mode == 1 && hipMemsetAsync(out, 0, sizeof(float) * total, st) != hipSuccess) return DVF_ERR_LAUNCH;
     a.out_mode = mode;
     if (mode == 2) { a.out = ws; a.ws_slice = total; }
-    if (const char *e = getenv("DVF_DBG")) a.dbg = atoi(e);
-    if (getenv("DVF_PIPE_DEBUG"))
+    if (const char *e = dvf_tune("DVF_DBG")) a.dbg = atoi(e);
+    dvf_plan_note(DVF_K_PIPE, pl.MT, pl.NT, pl.WM, 2 * pl.CKH, pl.TBU, a.KS, a.BN, a.NST, pl.threads, (int)pl.lds, mode | (a.ncls << 4));
+    if (dvf_tune("DVF_PIPE_DEBUG"))
         fprintf(stderr, "[pipe] M %d chunks %d N %d out %dx%d cls %d | MT %d NT %d WM %d CK %d TBU %d KS %d BN %d tile %dx%d "
                 "(sub %dx%d) grid %ux%ux%u lds %zu x%d mode %d\n", a.M, a.NCH, a.N, a.OH, a.OW, a.ncls, pl.MT, pl.NT, pl.WM,
                 2 * pl.CKH, pl.TBU, a.KS, a.BN, a.BH, a.BW, 1 << a.lsh, 1 << a.lsw, pl.grid.x, pl.grid.y, pl.grid.z, pl.lds, a.NST, mode);

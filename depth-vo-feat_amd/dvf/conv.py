@@ -142,6 +142,9 @@ def _packed_weights(weight, holder, desc, segc, kind):
     return buf, (_workspace(ent[2], weight.device) if ent[2] else None)
 
 
+GEOM_LOG = None   # set to a list(): ConvFn.forward appends the geometry of every call (tests: bench-shape parity)
+
+
 class ConvFn(torch.autograd.Function):
     """act(conv(cat(inputs), weight) + bias).  cfg = (k, stride, pad, opad, transposed, act, alpha, beta, out_hw)."""
 
@@ -168,6 +171,8 @@ class ConvFn(torch.autograd.Function):
         if out_hw is not None:                              # crop_like folded into the kernel
             oh, ow = min(oh, out_hw[0]), min(ow, out_hw[1])
         desc = L.ConvDesc(N, cin, H, W, cout, oh, ow, k, k, stride, pad, 1 if transposed else 0, act, alpha, beta)
+        if GEOM_LOG is not None:
+            GEOM_LOG.append((tuple(segc), cout, cfg, (N, H, W), tuple(ctx.needs_input_grad[3:])))
         out = torch.empty((N, cout, oh, ow), device=weight.device, dtype=torch.float32)
         # algorithmic MACs of this layer: kept pixels x taps actually contributing
         taps = k * k / (stride * stride) if transposed else k * k
@@ -186,6 +191,7 @@ class ConvFn(torch.autograd.Function):
                 L.check(L.lib().dvf_conv2d_fwd(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc),
                                                len(segc), L.dev(weight, "weight"), L.dev(bias, "bias"), L.dev(out),
                                                L.stream()), "dvf_conv2d_fwd")
+        L.note_plans("fwd")
         ctx.save_for_backward(weight, out, *inputs)
         ctx.desc, ctx.segc, ctx.has_bias = desc, segc, bias is not None
         return out
@@ -227,6 +233,7 @@ class ConvFn(torch.autograd.Function):
                 if rc == L.ERR_UNSUPPORTED:
                     L.check(lib.dvf_conv2d_dgrad(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins),
                                                  L.int_array(segc), len(segc), L.stream()), "dvf_conv2d_dgrad")
+            L.note_plans("dgrad")
         dw = None
         if need_w:
             arena = ctx.wparam is not None
@@ -238,6 +245,7 @@ class ConvFn(torch.autograd.Function):
                     L.check(lib.dvf_conv2d_wgrad(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
                                                  L.dev(dpre), L.dev(dw), 1 if arena else 0, L.stream()),
                             "dvf_conv2d_wgrad")
+                    L.note_plans("wgrad")
             if arena:
                 ctx.wparam._dvf_owner.grad_ready(ctx.wparam)
                 dw = None

@@ -39,6 +39,8 @@ MAX_VIEWS, MAX_SEGS = 4, 3
 SIGNATURES = {
     "dvf_version": (c_i, []),
     "dvf_error_string": (ctypes.c_char_p, [c_i]),
+    "dvf_build_has_tuning": (c_i, []),
+    "dvf_conv2d_last_plans": (c_i, [c_ip, c_i]),
     "dvf_inverse_warp_fwd": (c_i, [c_fp] * 6 + [c_i] * 4 + [c_u32, c_fp]),
     "dvf_inverse_warp_bwd": (c_i, [c_fp] * 10 + [c_i] * 4 + [c_u32, c_fp]),
     "dvf_pose_ws_floats": (c_i64, [c_i, c_i]),
@@ -183,6 +185,19 @@ class KernelTimer:
             d["flops"] += fl
             d["bytes"] += by
         return out
+
+
+PLAN_LOG = None  # set to a set(): every convolution call adds (op, plan record) of the kernels it launched
+
+
+def note_plans(op):
+    """Read the plan records of the convolution call just made on this thread into PLAN_LOG (tests only)."""
+    if PLAN_LOG is None:
+        return
+    buf = (ctypes.c_int * 96)()
+    n = lib().dvf_conv2d_last_plans(buf, 96)
+    for i in range(0, n, 12):
+        PLAN_LOG.add((op,) + tuple(buf[i:i + 12]))
 
 
 TIMER = None    # set to a KernelTimer() to record

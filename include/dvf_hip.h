@@ -50,6 +50,15 @@ extern "C" {
 
 int dvf_version(void);
 const char *dvf_error_string(int code);
+/* 1 when the library was built with -DDVF_TUNING (tuning knobs read from the environment, kernel ablation switches);
+ * the product build returns 0: it reads no environment variable and cannot be switched into computing partial results. */
+int dvf_build_has_tuning(void);
+/* Which kernels the LAST dvf_conv2d_* call of this thread launched: records of 12 ints
+ *   {kernel, MT, NT, WM, CK, TBU, KS, BN, NST, threads, lds_bytes, mode}   (kernel: 1 conv_pipe, 2 conv_gather,
+ *   3 head_fwd {C_out, nseg}, 4 head_dgrad, 5 head_wgrad, 6 conv_wgrad {MT, NTW, prefetch, CK, BH, PSPLIT, vec_p, stride,
+ *   threads, lds, KH*KW}, 7 head_seg_dgrad) copied to the HOST array `out`; returns the number of ints written.
+ * The planner is shape dependent; tests use this to show that every plan of the benchmark step is parity-tested. */
+int dvf_conv2d_last_plans(int *out, int max_ints);
 
 /* ---------------------------------------------------------------- inverse warp (image out)
  * Replaces inverse_warp.inverse_warp (pytorch_version/inverse_warp.py:160-193; copy at

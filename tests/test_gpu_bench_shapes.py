@@ -1,0 +1,162 @@
+"""Parity AT THE SHAPES THE BENCHMARK RUNS (cfg 2: 256x832, batch 4).
+
+The convolution planner is shape dependent (tile arrangement, NT, stage count / LDS budget, split-K factor, producer
+waves, wgrad channel chunks and vector paths all derive from N*H*W), so the toy-size cases of test_gpu_conv.py do not
+prove the kernel variants the headline number runs on.  Here:
+
+  1. one full-size training step (DispNetS + PoseExpNet, photometric V=2 + 10*smooth) is compared with the CPU oracle
+     -- per-term losses and every parameter's gradient -- while every convolution geometry of the step and every plan
+     record the library reports (dvf_conv2d_last_plans) is collected;
+  2. every distinct convolution geometry of that step is run alone (forward, dgrad of the segments that need it, wgrad,
+     bias grad) against torch CPU conv2d / conv_transpose2d at 1e-4;
+  3. the set of plans hit in 2 must contain the set the step used in 1.
+Bound: 1e-4 relative (max-abs error / max-abs reference) per layer; for the step, losses at 1e-4 and gradients by
+norm at 1e-4 and by norm of the difference at 1e-3 (a few of the 852K pixels sit on a bilinear tap-set crossing or an L1
+kink where two correct fp32 implementations may pick different sides; measured values are printed)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from oracle import nets as onets
+from oracle import steps as osteps
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda"
+B, H, W = 4, 256, 832
+STATE = {}
+
+
+def _ref_act(x, act, alpha, beta):
+    if act == 1:
+        return F.relu(x)
+    if act == 2:
+        return alpha * torch.sigmoid(x) + beta
+    return x
+
+
+def _step_nets():
+    import DispNetS
+    import PoseExpNet
+    dsd = onets.fill_params(onets.dispnet_layers(), seed=1)
+    psd = onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2)
+    disp, pose = DispNetS.DispNetS(), PoseExpNet.PoseExpNet(output_exp=True)
+    disp.load_state_dict({k: v.clone() for k, v in dsd.items()})
+    pose.load_state_dict({k: v.clone() for k, v in psd.items()})
+    return dsd, psd, disp.to(DEV).train(), pose.to(DEV).train()
+
+
+def test_fullsize_step_vs_oracle():
+    """cfg-2 step at the benchmark size through FlatAdam's arena (weight gradients accumulate in place on the side
+    streams, exactly as bench.py runs it) vs oracle.steps.step_unsupervise(do_update=False)."""
+    from dvf import conv as C
+    from dvf import lib as L
+    from dvf.engine import FlatAdam
+    from dvf.steps import unsupervise_losses
+    from dvf.synthetic import synthetic_batch
+    dsd, psd, disp, pose = _step_nets()
+    opt = FlatAdam(list(pose.parameters()) + list(disp.parameters()), lr=1e-3, weight_decay=1e-8)
+    batch = synthetic_batch(B, H, W, seed=1234, device=DEV)
+    C.GEOM_LOG, L.PLAN_LOG = [], set()
+    try:
+        loss, terms = unsupervise_losses(disp, pose, batch)
+        opt.zero_grad()
+        loss.backward()
+        opt.join_wgrad()
+        L.join_aux_streams()
+        torch.cuda.synchronize()
+    finally:
+        STATE["geoms"], STATE["step_plans"] = C.GEOM_LOG, L.PLAN_LOG
+        C.GEOM_LOG, L.PLAN_LOG = None, None
+    ref, grads, _ = osteps.step_unsupervise(dsd, psd, osteps.synthetic_batch(B, H, W, seed=1234), do_update=False)
+    for k in ("img", "smooth", "total"):
+        assert rel_err(terms[k], ref[k]) < TOL, (k, float(terms[k]), float(ref[k]))
+    worst = (0.0, 0.0, "")
+    for name, mod in (("disp", disp), ("pose", pose)):
+        for k, p in mod.named_parameters():
+            if k not in grads[name]:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                continue
+            r = grads[name][k].double()
+            g = p.grad.detach().double().cpu()
+            rn = max(float(r.norm()), 1e-30)
+            e_norm, e_diff = abs(float(g.norm()) - rn) / rn, float((g - r).norm()) / rn
+            worst = max(worst, (e_diff, e_norm, f"{name}.{k}"))
+            assert e_norm < TOL, (name, k, e_norm)
+            assert e_diff < 1e-3, (name, k, e_diff)
+    print("worst gradient: |g-ref|/|ref| = %.2e, norm error %.2e at %s" % worst)
+
+
+def _distinct(geoms):
+    seen, out = set(), []
+    for g in geoms:
+        if g not in seen:
+            seen.add(g)
+            out.append(g)
+    return out
+
+
+def test_every_bench_layer_geometry():
+    """Forward / dgrad / wgrad / bias-grad of every distinct convolution geometry of the cfg-2 step at batch 4."""
+    from dvf import lib as L
+    from dvf.conv import ConvFn
+    if "geoms" not in STATE:
+        test_fullsize_step_vs_oracle()
+    geoms = _distinct(STATE["geoms"])
+    assert len(geoms) >= 40, len(geoms)            # DispNetS: 14 + 7 + 7 + 4, PoseExpNet: 7 + 1 + 5 + 4 (some coincide)
+    L.PLAN_LOG = set()
+    failures = []
+    try:
+        for gi, (segs, cout, cfg, (n, h, w), need_in) in enumerate(geoms):
+            k, stride, pad, opad, transposed, act, alpha, beta, out_hw = cfg
+            gen = torch.Generator().manual_seed(1000 + gi)
+            cin = sum(segs)
+            xs = [torch.randn(n, c, h, w, generator=gen) for c in segs]
+            wshape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+            wt = torch.randn(wshape, generator=gen) / (cin * k * k) ** 0.5
+            b = torch.randn(cout, generator=gen) * 0.1
+            rx = [x.clone().requires_grad_(ng) for x, ng in zip(xs, need_in)]
+            rw, rb = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            xin = torch.cat(rx, 1)
+            if transposed:
+                pre = F.conv_transpose2d(xin, rw, rb, stride=stride, padding=pad, output_padding=opad)
+            else:
+                pre = F.conv2d(xin, rw, rb, stride=stride, padding=pad)
+            if out_hw is not None:
+                pre = pre[:, :, :out_hw[0], :out_hw[1]]
+            ref = _ref_act(pre, act, alpha, beta)
+            gout = torch.randn(ref.shape, generator=gen)
+            if act == 1:
+                gout = gout * (pre.detach().abs() > 1e-4)       # ReLU kink: see test_gpu_conv.py
+            (ref * gout).sum().backward()
+            gx = [x.clone().to(DEV).requires_grad_(ng) for x, ng in zip(xs, need_in)]
+            gw, gb = wt.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+            out = ConvFn.apply(gw, gb, cfg, *gx)
+            (out * gout.to(DEV)).sum().backward()
+            tag = f"{'T' if transposed else 'C'}{k}x{k}s{stride} {list(segs)}->{cout} @{h}x{w} N{n}"
+            errs = {"fwd": rel_err(out, ref), "wgrad": rel_err(gw.grad, rw.grad), "bias": rel_err(gb.grad, rb.grad)}
+            for i, (a, r) in enumerate(zip(gx, rx)):
+                if r.grad is not None:
+                    errs[f"dgrad{i}"] = rel_err(a.grad, r.grad)
+            bad = {kk: v for kk, v in errs.items() if not v < TOL}
+            if bad or tuple(out.shape) != tuple(ref.shape):
+                failures.append((tag, bad))
+            del out, gx, gw, gb, rx, rw, rb, ref, pre, gout
+    finally:
+        STATE["layer_plans"] = L.PLAN_LOG
+        L.PLAN_LOG = None
+    assert not failures, failures
+
+
+def test_bench_plans_are_the_tested_plans():
+    """Every (op, kernel, tiling) record of the full-size step also ran in a per-layer parity case."""
+    if "layer_plans" not in STATE:
+        test_every_bench_layer_geometry()
+    step, layer = STATE["step_plans"], STATE["layer_plans"]
+    assert step, "the library reported no plans"
+    missing = sorted(step - layer)
+    assert not missing, missing
+    kernels = {p[1] for p in step}
+    assert {1, 6} <= kernels, kernels                      # conv_pipe and conv_wgrad at least
+    print("%d distinct plans in the step, all parity-tested; kernels used: %s" % (len(step), sorted(kernels)))
