@@ -65,8 +65,8 @@ class PoseExpNet(_PoseExpBase):
     def forward(self, target_image, ref_imgs):
         assert(len(ref_imgs) == self.nb_ref_imgs)
         frames = [target_image] + list(ref_imgs)
-        if len(frames) > _L.MAX_SEGS:                                        # > 3 frames: pack once
-            frames = torch.cat(frames, 1)
+        if len(frames) > _L.MAX_SEGS:         # the first convolution walks up to 5 frames (nb_ref_imgs <= 4) in place
+            raise ValueError(f"nb_ref_imgs = {self.nb_ref_imgs}: at most {_L.MAX_SEGS - 1} reference images are supported")
         masks, pose = self._run(frames)
         pose = pose.view(pose.size(0), self.nb_ref_imgs, 6)
         if self.training:

@@ -32,9 +32,10 @@ __device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__
 // computes the dgrad of a narrow input segment (m = segment channel, c = output channel of the convolution, taps flipped).
 // Tile 64 x 8 pixels, two rows per thread; the per-thread staging offsets are channel-invariant.
 constexpr int FT_H = 8, FP_H = FT_H + 2, FP_N = FP_H * HP_W, F_LD = (FP_N + 255) / 256;
-struct HeadSegs {                            // the input: a virtual concat of up to DVF_MAX_SEGS tensors
-    const float *p[DVF_MAX_SEGS];
-    int c[DVF_MAX_SEGS];
+constexpr int HEAD_MAX_SEGS = 3;             // (the thin layers these kernels serve concatenate at most three tensors)
+struct HeadSegs {                            // the input: a virtual concat of up to HEAD_MAX_SEGS tensors
+    const float *p[HEAD_MAX_SEGS];
+    int c[HEAD_MAX_SEGS];
     int n;
 };
 template <int MO>
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const 
     for (int m = 0; m < MO; ++m) acc[0][m] = acc[1][m] = bias ? bias[m] : 0.f;
     // the loads of chunk c0 + HCK are issued before the FMAs of chunk c0 (registers), so their latency overlaps them
     float stg[HCK][F_LD];
-    static_assert(DVF_MAX_SEGS == 3, "segment select below");
+    static_assert(HEAD_MAX_SEGS == 3, "segment select below");
     auto seg_ptr = [&](int sg) { return sg == 0 ? in.p[0] : sg == 1 ? in.p[1] : in.p[2]; };
     auto seg_ch = [&](int sg) { return sg == 0 ? in.c[0] : sg == 1 ? in.c[1] : in.c[2]; };
     auto issue = [&](int sg, int cs) {       // chunk = up to HCK channels of ONE segment, starting at its channel cs
@@ -248,7 +249,7 @@ int dvf_head_fwd(const dvf_conv_desc *d, const float *in, const float *w, const 
 // Thin full-resolution layers (iconv1: 16+1 -> 16 channels at the input resolution, DispNetS.py:126): a 32-row MFMA tile
 // is half padding and the reduction (153 deep) too short to amortise a tile's prologue, so the direct kernel is ~2x faster.
 bool dvf_head_wide_applicable(const dvf_conv_desc *d, int nseg) {
-    return nseg >= 1 && nseg <= DVF_MAX_SEGS && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
+    return nseg >= 1 && nseg <= HEAD_MAX_SEGS && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
            d->C_out == 16 && d->C_in <= 24 && d->H_out == d->H_in && d->W_out == d->W_in &&
            (int64_t)d->H_in * d->W_in >= 64 * 64 && dvf_tune("DVF_NO_HEAD") == nullptr && dvf_tune("DVF_NO_WIDE_HEAD") == nullptr;
 }
@@ -258,7 +259,7 @@ int dvf_head_fwd_segs(const dvf_conv_desc *d, const float *const *in_segs, const
     const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, FT_H);
     const dim3 grid(tilesX * tilesY, d->N);
     HeadSegs in{};
-    for (int s = 0; s < DVF_MAX_SEGS; ++s) { in.p[s] = s < nseg ? in_segs[s] : in_segs[0]; in.c[s] = s < nseg ? seg_channels[s] : 0; }
+    for (int s = 0; s < HEAD_MAX_SEGS; ++s) { in.p[s] = s < nseg ? in_segs[s] : in_segs[0]; in.c[s] = s < nseg ? seg_channels[s] : 0; }
     in.n = nseg;
     HEAD_FWD_DISPATCH(d->C_out, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_in * 9 * 4, st>>>(
                                     in, w, bias, out, d->C_in, d->H_in, d->W_in, tilesX, d->act, d->alpha, d->beta, d->C_in * 9, 9, 0)));
@@ -284,7 +285,7 @@ int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w
     const dim3 grid(tilesX * tilesY, d->N);
     const float *wseg = w + (int64_t)seg_off * 9;
     HeadSegs in{};
-    for (int s = 0; s < DVF_MAX_SEGS; ++s) { in.p[s] = dpre; in.c[s] = s == 0 ? d->C_out : 0; }
+    for (int s = 0; s < HEAD_MAX_SEGS; ++s) { in.p[s] = dpre; in.c[s] = s == 0 ? d->C_out : 0; }
     in.n = 1;
     HEAD_FWD_DISPATCH(segc, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_out * 9 * 4, st>>>(
                                 in, wseg, nullptr, din, d->C_out, d->H_in, d->W_in, tilesX, DVF_ACT_NONE, 1.f, 0.f, 9, d->C_in * 9, 1)));

@@ -33,7 +33,7 @@ c_ip = ctypes.POINTER(ctypes.c_int)
 
 ROT_QUAT, PAD_BORDER, ALIGN_CORNERS, POSE_SE3, PIXEL_COORDS = 1, 2, 4, 8, 16
 ACT_NONE, ACT_RELU, ACT_SIGMOID_AFFINE = 0, 1, 2
-MAX_VIEWS, MAX_SEGS = 4, 3
+MAX_VIEWS, MAX_SEGS = 4, 5
 
 # name -> (restype, argtypes); kept in one table so tests can check every declared symbol is exported
 SIGNATURES = {

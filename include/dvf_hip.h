@@ -46,7 +46,7 @@ extern "C" {
 #define DVF_ACT_SIGMOID_AFFINE 2 /* alpha * sigmoid(x) + beta  (DispNetS.py:112; masks use alpha=1, beta=0) */
 
 #define DVF_MAX_VIEWS 4
-#define DVF_MAX_SEGS 3
+#define DVF_MAX_SEGS 5
 
 int dvf_version(void);
 const char *dvf_error_string(int code);

@@ -215,10 +215,16 @@ def gen_nets():
          **grad_digest({k: p.grad for k, p in net.named_parameters()}))
 
 
-def param_digest(sd):
+def param_digest(sd, sd0=None):
+    """Per-parameter sum and norm; with the initial values `sd0` also sum and norm of the UPDATE (p - p0): after two
+    Adam steps every element has moved by ~2*lr, so these two bind where the parameter's own norm barely changes."""
     keys = sorted(sd)
-    return (np.array(keys), np.array([float(sd[k].double().sum()) for k in keys]),
-            np.array([float(sd[k].double().norm()) for k in keys]))
+    out = [np.array(keys), np.array([float(sd[k].double().sum()) for k in keys]),
+           np.array([float(sd[k].double().norm()) for k in keys])]
+    if sd0 is not None:
+        out += [np.array([float((sd[k].double() - sd0[k].double()).sum()) for k in keys]),
+                np.array([float((sd[k].double() - sd0[k].double()).norm()) for k in keys])]
+    return out
 
 
 def gen_steps():
@@ -274,44 +280,72 @@ def gen_steps():
                 rec["T21_0"] = _np(T21)
             opt.step()
             rec[f"img{it}"], rec[f"smooth{it}"], rec[f"total{it}"] = _np(img_l), _np(sm_l), _np(loss)
+        init = {"disp": onets.fill_params(onets.dispnet_layers(), seed=1), "pose": onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2),
+                "feat": onets.fill_params(onets.featnet_layers(), seed=3)}
         for name, net in (("disp", disp_net), ("pose", pose_net)) + ((("feat", feat_net),) if with_feat else ()):
-            k, s, n = param_digest(net.state_dict())
+            k, s, n, ds, dn = param_digest(net.state_dict(), init[name])
             rec[f"p_{name}_keys"], rec[f"p_{name}_sums"], rec[f"p_{name}_norms"] = k, s, n
+            rec[f"p_{name}_dsums"], rec[f"p_{name}_dnorms"] = ds, dn
         save("step_unsup_feat" if with_feat else "step_unsup", **rec, b=b, h=h, w=w)
 
-    # ---- train.py-style (sfm; cfg 4/5 family)
-    batch = osteps.synthetic_batch(b, h, w, seed=1234)
-    disp_net, pose_net = ref_disp.DispNetS(), ref_pose_sfm.PoseExpNet(nb_ref_imgs=2, output_exp=True)
-    disp_net.load_state_dict(onets.fill_params(onets.dispnet_layers(), seed=1))
-    pose_net.load_state_dict(onets.fill_params(onets.posenet_layers(9, 12, 2, True), seed=2))
-    disp_net.train(); pose_net.train()
-    opt = torch.optim.Adam([{"params": disp_net.parameters(), "lr": 2e-4},
-                            {"params": pose_net.parameters(), "lr": 2e-4}], betas=(0.9, 0.999), weight_decay=0)
-    rec = {}
-    for it in range(2):
-        tgt, refs = batch["img_R2"], [batch["img_R1"], batch["img_L2"]]
-        disps = disp_net(tgt)
-        depth = [1 / d for d in disps]
-        masks, pose = pose_net(tgt, refs)
-        l1 = ref_sfm.photometric_reconstruction_loss(tgt, refs, batch["K"], batch["Kinv"], depth, masks, pose,
-                                                     "euler", "zeros")
-        l3 = ref_sfm.smooth_loss(depth, 2.0)
-        l4 = F.mse_loss(pose[:, 1], batch["T_R2L"])
-        loss = 1.0 * l1 + 0.1 * l3 + l4
-        opt.zero_grad()
-        loss.backward()
-        if it == 0:
-            rec.update({"g_disp_" + k: v for k, v in grad_digest(
-                {k: p.grad for k, p in disp_net.named_parameters() if p.grad is not None}).items()})
-            rec.update({"g_pose_" + k: v for k, v in grad_digest(
-                {k: p.grad for k, p in pose_net.named_parameters() if p.grad is not None}).items()})
-            rec["pose_0"] = _np(pose)
-        opt.step()
-        rec[f"photo{it}"], rec[f"smooth{it}"], rec[f"lr{it}"], rec[f"total{it}"] = _np(l1), _np(l3), _np(l4), _np(loss)
-    for name, net in (("disp", disp_net), ("pose", pose_net)):
-        k, s, n = param_digest(net.state_dict())
-        rec[f"p_{name}_keys"], rec[f"p_{name}_sums"], rec[f"p_{name}_norms"] = k, s, n
-    save("step_train_sfm", **rec, b=b, h=h, w=w)
+    # ---- train.py-style (sfm; cfg 4/5 family): the base case, with the explainability term (w2 > 0, train.py:195),
+    # and with nb_ref_imgs = 4 (cfg 5: five-frame window -> 15-channel pose network input, V = 4 warps per scale)
+    for tag, nb_ref, w2, bb in (("step_train_sfm", 2, 0.0, b), ("step_train_sfm_exp", 2, 0.2, b), ("step_train_sfm_v4", 4, 0.2, 1)):
+        batch = osteps.synthetic_batch(bb, h, w, seed=1234, n_views=nb_ref)
+        disp_net, pose_net = ref_disp.DispNetS(), ref_pose_sfm.PoseExpNet(nb_ref_imgs=nb_ref, output_exp=True)
+        disp_net.load_state_dict(onets.fill_params(onets.dispnet_layers(), seed=1))
+        pose_net.load_state_dict(onets.fill_params(onets.posenet_layers(3 * (1 + nb_ref), 6 * nb_ref, nb_ref, True), seed=2))
+        disp_net.train(); pose_net.train()
+        opt = torch.optim.Adam([{"params": disp_net.parameters(), "lr": 2e-4},
+                                {"params": pose_net.parameters(), "lr": 2e-4}], betas=(0.9, 0.999), weight_decay=0)
+        rec = {}
+        for it in range(2):
+            tgt, refs = batch["img_R2"], [batch["img_R1"], batch["img_L2"]] + list(batch["extra_refs"])[:nb_ref - 2]
+            disps = disp_net(tgt)
+            depth = [1 / d for d in disps]
+            masks, pose = pose_net(tgt, refs)
+            l1 = ref_sfm.photometric_reconstruction_loss(tgt, refs, batch["K"], batch["Kinv"], depth, masks, pose,
+                                                         "euler", "zeros")
+            l2 = ref_sfm.explainability_loss(masks) if w2 > 0 else 0
+            l3 = ref_sfm.smooth_loss(depth, 2.0)
+            l4 = F.mse_loss(pose[:, 1], batch["T_R2L"])
+            loss = 1.0 * l1 + w2 * l2 + 0.1 * l3 + l4
+            opt.zero_grad()
+            loss.backward()
+            if it == 0:
+                rec.update({"g_disp_" + k: v for k, v in grad_digest(
+                    {k: p.grad for k, p in disp_net.named_parameters() if p.grad is not None}).items()})
+                rec.update({"g_pose_" + k: v for k, v in grad_digest(
+                    {k: p.grad for k, p in pose_net.named_parameters() if p.grad is not None}).items()})
+                rec["pose_0"] = _np(pose)
+            opt.step()
+            rec[f"photo{it}"], rec[f"smooth{it}"], rec[f"lr{it}"], rec[f"total{it}"] = _np(l1), _np(l3), _np(l4), _np(loss)
+            if w2 > 0:
+                rec[f"exp{it}"] = _np(l2)
+        init = {"disp": onets.fill_params(onets.dispnet_layers(), seed=1),
+                "pose": onets.fill_params(onets.posenet_layers(3 * (1 + nb_ref), 6 * nb_ref, nb_ref, True), seed=2)}
+        for name, net in (("disp", disp_net), ("pose", pose_net)):
+            k, s, n, ds, dn = param_digest(net.state_dict(), init[name])
+            rec[f"p_{name}_keys"], rec[f"p_{name}_sums"], rec[f"p_{name}_norms"] = k, s, n
+            rec[f"p_{name}_dsums"], rec[f"p_{name}_dnorms"] = ds, dn
+        save(tag, **rec, b=bb, h=h, w=w, nb_ref=nb_ref, w2=w2)
+
+
+def gen_metrics():
+    """Depth metrics of the reference (loss_functions_sfm.compute_errors, :80-116): KITTI-like sparse ground truth
+    (0 = no LiDAR return, some values beyond 80 m) against a noisy, differently scaled prediction."""
+    import loss_functions_sfm as ref_sfm
+    g = torch.Generator().manual_seed(41)
+    n, hh, ww = 3, 96, 320
+    gt = torch.rand(n, hh, ww, generator=g, dtype=torch.float64) * 95.0
+    gt = torch.where(torch.rand(n, hh, ww, generator=g, dtype=torch.float64) < 0.7, torch.zeros_like(gt), gt).float()
+    pred = (gt.double() * 0.37 * (1 + 0.25 * torch.randn(n, hh, ww, generator=g, dtype=torch.float64)) +
+            torch.rand(n, hh, ww, generator=g, dtype=torch.float64) * 0.5).float()
+    pred[0, :4] = -1.0                      # exercises the clamp(1e-3, 80)
+    out = {}
+    for crop in (True, False):
+        out["crop" if crop else "full"] = np.array(ref_sfm.compute_errors(gt, pred, crop=crop), dtype=np.float64)
+    save("metrics_compute_errors", gt=_np(gt), pred=_np(pred), **out)
 
 
 def gen_se3():
@@ -338,11 +372,12 @@ def main():
     torch.manual_seed(0)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")      # grid_sample align_corners default-change warning
-        gen_warp()
-        gen_losses()
-        gen_nets()
-        gen_steps()
-        gen_se3()
+        groups = {"warp": gen_warp, "losses": gen_losses, "nets": gen_nets, "steps": gen_steps, "metrics": gen_metrics,
+                  "se3": gen_se3}
+        only = [a for a in sys.argv[1:] if a in groups]
+        for name, fn in groups.items():          # usage: gen_golden.py [group ...]   (default: all)
+            if not only or name in only:
+                fn()
 
 
 if __name__ == "__main__":
