@@ -70,6 +70,8 @@ class FlatAdam:
             for p in b["params"]:
                 p._dvf_bucket = bi
         self._comm_stream = torch.cuda.Stream(device=dev) if (self.exchange and self.overlap and dev.type == "cuda") else None
+        self._main_stream = None     # compute stream of the step (recorded by zero_grad)
+        self.n_reduced = 0           # buckets exchanged so far (tests / bench bookkeeping)
         self._ranges = None
         self._reset_pending()
         self.side = torch.cuda.Stream(device=dev) if (wgrad_stream and dev.type == "cuda") else None
@@ -125,21 +127,28 @@ class FlatAdam:
         grads = self.flat_g[b["start"]:b["end"]]
         if self._comm_stream is None:                       # CPU tensors (gloo) or overlap=False: current stream
             dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
+            self.n_reduced += 1
             return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        with torch.cuda.stream(self._comm_stream):
-            self._comm_stream.wait_event(ev)
-            if self._side_dirty:
-                for side in self._sides.values():             # the bucket's weight gradients come from the side streams
-                    self._comm_stream.wait_stream(side)
-            for dev, aux in L.AUX_STREAMS.items():            # ... or from a sub-network on the auxiliary stream
-                if dev == self._comm_stream.device:
-                    self._comm_stream.wait_stream(aux)
+        # The bucket's gradients were written by kernels on EVERY compute stream of the step: bias gradients and thin
+        # layers on the stream the layer's backward ran on (the main stream for the depth network, the auxiliary stream
+        # for the pose network), weight gradients on the side stream behind each of the two.  The exchange waits for all.
+        comm = self._comm_stream
+        comm.wait_stream(torch.cuda.current_stream())         # the stream this grad_ready() was called on
+        if self._main_stream is not None:
+            comm.wait_stream(self._main_stream)               # the stream zero_grad()/backward() were issued from
+        for side in self._sides.values():
+            comm.wait_stream(side)
+        for dev, aux in L.AUX_STREAMS.items():
+            if dev == comm.device:
+                comm.wait_stream(aux)
+        with torch.cuda.stream(comm):
             dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
+        self.n_reduced += 1
 
     # ------------------------------------------------------------------ optimizer API
     def zero_grad(self):
+        if self.flat_g.is_cuda:
+            self._main_stream = torch.cuda.current_stream()
         L.join_aux_streams()
         self.join_wgrad()
         self.flat_g.zero_()

@@ -79,6 +79,86 @@ def test_flat_arena_exchange_world2():
     assert sorted(results) == [(0, "ok"), (1, "ok")], results
 
 
+class _FakeStream:
+    """Stands in for torch.cuda.Stream on a CPU box: records what it was told to wait for."""
+
+    def __init__(self, name, device="cpu"):
+        self.name, self.device, self.waited = name, device, []
+
+    def wait_stream(self, other):
+        self.waited.append(other.name)
+
+
+def _worker_overlap(rank, world, port, q):
+    for p in (ROOT, PKG):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import contextlib
+        from dvf import lib as L
+        from dvf.engine import FlatAdam
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.randn(n)) for n in (3000, 3000, 3000)]
+        opt = FlatAdam(params, lr=1e-3, world_size=world, bucket_mb=0.01)
+        assert len(opt.buckets) == 3
+        # mock the GPU streams of the overlapped exchange: communication stream, the step's main stream, the stream a
+        # backward node runs on, one weight-gradient side stream, one auxiliary (pose network) stream
+        comm, main, cur, side, aux = (_FakeStream(n) for n in ("comm", "main", "current", "side", "aux"))
+        opt._comm_stream, opt._main_stream, opt._sides = comm, main, {1: side}
+        L.AUX_STREAMS["cpu"] = aux
+        order = []
+        real_all_reduce = dist.all_reduce
+
+        def spy_all_reduce(t, **kw):
+            order.append(("all_reduce", tuple(comm.waited)))
+            return real_all_reduce(t, **kw)
+
+        torch.cuda.current_stream = lambda *a, **k: cur
+        torch.cuda.stream = lambda s: contextlib.nullcontext()
+        dist.all_reduce = spy_all_reduce
+        for step in range(2):
+            comm.waited.clear()
+            order.clear()
+            opt.zero_grad()
+            opt._main_stream = main                             # (zero_grad records it only for GPU arenas)
+            for p in opt.params:
+                p._dvf_grad.add_(float(rank + 1))
+                opt.grad_ready(p)
+            launched = len(order)
+            opt.synchronize_grads()
+            assert cur.waited[-1] == "comm"                     # the compute stream joins the exchange before Adam
+            # step 0: the touched set is unknown during backward -> nothing launches early; step 1: every bucket does
+            assert launched == (0 if step == 0 else 3), (step, launched)
+            assert len(order) == 3
+            for _, waited in order:                             # every exchange waited for ALL compute streams first
+                assert {"current", "main", "side", "aux"} <= set(waited), waited
+            for p in params:
+                assert torch.allclose(p.grad, torch.full_like(p, 3.0))
+        q.put((rank, "ok"))
+    except Exception as e:                                     # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e} | " + " / ".join(traceback.format_exc().splitlines()[-4:])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_exchange_waits_for_every_compute_stream_world2():
+    """The bucket launched from inside backward must wait for the main stream, the stream of the backward node, the
+    weight-gradient side streams and the auxiliary stream before its all-reduce (streams mocked on CPU; the same code
+    path runs on the GPU under tests/test_gpu_ddp.py)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
 def test_weak_scaling_gradient_identity():
     """every loss term is a mean over B*C*H*W including masked pixels, so with equal local batches
     the rank-average of local-mean gradients equals the global-batch gradient.  Checked with the CPU oracle."""

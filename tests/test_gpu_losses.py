@@ -66,6 +66,45 @@ def test_smooth_golden():
         assert rel_err(maps[s].grad, g[f"g_multi{s}"]) < 1e-5
 
 
+@pytest.mark.parametrize("pad", ["zeros", "border", "nomask"])
+def test_photometric_sfm_golden(pad):
+    """loss_functions_sfm.photometric_reconstruction_loss (4 scales, 2 views, masks | no masks, zeros | border) and
+    explainability_loss on the HIP path against the reference's vectors (loss_functions_sfm.py:9-56)."""
+    import loss_functions_sfm as ls
+    g = load_golden("photo_sfm_zeros" if pad == "nomask" else f"photo_sfm_{pad}")
+    depth = [t(g[f"depth{s}"], DEV).requires_grad_(True) for s in range(4)]
+    masks = [t(g[f"mask{s}"], DEV).requires_grad_(True) for s in range(4)]
+    pose = t(g["pose"], DEV).requires_grad_(True)
+    refs = [t(g["ref0"], DEV), t(g["ref1"], DEV)]
+    if pad == "nomask":
+        gn = load_golden("photo_sfm_nomask")
+        loss = ls.photometric_reconstruction_loss(t(g["tgt"], DEV), refs, t(g["K"], DEV), t(g["Kinv"], DEV), depth,
+                                                  [None] * 4, pose, "euler", "zeros")
+        loss.backward()
+        assert rel_err(loss, gn["loss"]) < TOL
+        assert rel_err(pose.grad, gn["g_pose"]) < TOL
+        for s in range(4):
+            assert rel_err(depth[s].grad, gn[f"g_depth{s}"]) < TOL, s
+        return
+    loss = ls.photometric_reconstruction_loss(t(g["tgt"], DEV), refs, t(g["K"], DEV), t(g["Kinv"], DEV), depth, masks,
+                                              pose, "euler", pad)
+    loss.backward()
+    assert rel_err(loss, g["loss"]) < TOL
+    assert rel_err(pose.grad, g["g_pose"]) < TOL
+    for s in range(4):
+        assert rel_err(depth[s].grad, g[f"g_depth{s}"]) < TOL, s
+        assert rel_err(masks[s].grad, g[f"g_mask{s}"]) < TOL, s
+    for m in masks:
+        m.grad = None
+    le = ls.explainability_loss(masks)                      # sum_s BCE(mask_s, 1)  (:49-56)
+    le.backward()
+    assert rel_err(le, g["exp_loss"]) < 1e-5
+    for s in range(4):
+        assert rel_err(masks[s].grad, g[f"g_mask_exp{s}"]) < 1e-5, s
+    single = ls.explainability_loss(masks[0].detach())      # a bare tensor is accepted like a 1-list (:50-51)
+    assert single.dim() == 0 and float(single) > 0
+
+
 def _kitti_K(b, h, w):
     K = torch.tensor([[0.58 * w, 0, 0.5 * w], [0, 1.92 * h, 0.5 * h], [0, 0, 1.0]]).expand(b, 3, 3).contiguous()
     return K, torch.inverse(K[0]).expand(b, 3, 3).contiguous()

@@ -70,23 +70,37 @@ def test_posenet_golden(tag):
     assert torch.is_tensor(m1)          # eval mode returns only the finest mask (PoseExpNet_sfm.py:92-95)
 
 
-def _check_params(g, name, module, lr, n_steps=2):
+def _check_params(g, name, module, sd0, lr, n_steps=2):
+    """Post-Adam parameters vs the reference run (see tests/test_oracle_golden.py::_check_params): norm at 1e-4, and
+    the UPDATE p - p0 by norm (1e-3) and by sum (1e-3 of its norm + 2*lr*n_steps*(2 + 1e-5*numel) for sign flips of
+    noise-level gradients)."""
     sd = {k: v.detach().double().cpu() for k, v in module.state_dict().items()}
     keys = [str(k) for k in g[f"p_{name}_keys"]]
     assert sorted(sd) == keys
     for i, k in enumerate(keys):
         n = float(g[f"p_{name}_norms"][i])
         assert abs(float(sd[k].norm()) - n) / max(n, 1e-12) < TOL, k
-        flip = 2 * lr * n_steps * (1 + 1e-3 * sd[k].numel())     # see tests/test_oracle_golden.py::_check_params
-        assert abs(float(sd[k].sum()) - float(g[f"p_{name}_sums"][i])) < TOL * n + flip, k
+        upd = sd[k] - sd0[k].double()
+        dn, ds = float(g[f"p_{name}_dnorms"][i]), float(g[f"p_{name}_dsums"][i])
+        assert abs(float(upd.norm()) - dn) <= 1e-3 * dn, (k, float(upd.norm()), dn)
+        flip = 2 * lr * n_steps * (2 + 1e-5 * upd.numel())
+        assert abs(float(upd.sum()) - ds) <= 1e-3 * dn + flip, (k, float(upd.sum()), ds)
 
 
-def _batch(b, h, w):
+def _init(kind, *a):
+    return {"disp": lambda: onets.fill_params(onets.dispnet_layers(), seed=1),
+            "pose": lambda: onets.fill_params(onets.posenet_layers(*a), seed=2),
+            "feat": lambda: onets.fill_params(onets.featnet_layers(), seed=3)}[kind]()
+
+
+def _batch(b, h, w, n_views=2):
     from dvf.synthetic import synthetic_batch
-    prod = synthetic_batch(b, h, w, seed=1234, device=DEV)
-    ref = osteps.synthetic_batch(b, h, w, seed=1234)
+    prod = synthetic_batch(b, h, w, seed=1234, device=DEV, n_views=n_views)
+    ref = osteps.synthetic_batch(b, h, w, seed=1234, n_views=n_views)
     for k in ("img_R2", "img_R1", "img_L2", "K", "Kinv", "T_R2L"):     # product recipe == oracle recipe
         assert torch.equal(prod[k].cpu(), ref[k])
+    for a, r in zip(prod["extra_refs"], ref["extra_refs"]):
+        assert torch.equal(a.cpu(), r)
     return prod
 
 
@@ -114,36 +128,39 @@ def test_step_unsupervise_golden():
         assert rel_err(terms["img"], g[f"img{it}"]) < TOL
         assert rel_err(terms["smooth"], g[f"smooth{it}"]) < TOL
         assert rel_err(terms["total"], g[f"total{it}"]) < TOL
-    _check_params(g, "disp", disp, 1e-3)
-    _check_params(g, "pose", pose, 1e-3)
+    _check_params(g, "disp", disp, _init("disp"), 1e-3)
+    _check_params(g, "pose", pose, _init("pose", 6, 6, 2, True), 1e-3)
 
 
-def test_step_train_sfm_golden():
-    """Two full iterations of the train.py body (4 scales, masks, smooth, stereo-pose MSE)."""
+@pytest.mark.parametrize("name", ["step_train_sfm", "step_train_sfm_exp", "step_train_sfm_v4"])
+def test_step_train_sfm_golden(name):
+    """Two full iterations of the train.py body (4 scales, masks, smooth, stereo-pose MSE): the base case, with the
+    explainability term switched on (w2 = 0.2, train.py:195 -> dvf_bce_ones_*), and with nb_ref_imgs = 4 (cfg 5: five
+    frames walked in place by the first pose convolution, V = 4 warps per fused loss launch)."""
     import DispNetS
     import PoseExpNet_sfm
     from dvf.engine import FlatAdam
     from dvf.steps import train_sfm_losses
-    g = load_golden("step_train_sfm")
-    b, h, w = int(g["b"]), int(g["h"]), int(g["w"])
-    batch = _batch(b, h, w)
-    disp = _load(DispNetS.DispNetS(), onets.fill_params(onets.dispnet_layers(), seed=1))
-    pose = _load(PoseExpNet_sfm.PoseExpNet(nb_ref_imgs=2, output_exp=True),
-                 onets.fill_params(onets.posenet_layers(9, 12, 2, True), seed=2))
+    g = load_golden(name)
+    b, h, w, nb_ref, w2 = int(g["b"]), int(g["h"]), int(g["w"]), int(g["nb_ref"]), float(g["w2"])
+    batch = _batch(b, h, w, n_views=nb_ref)
+    pargs = (3 * (1 + nb_ref), 6 * nb_ref, nb_ref, True)
+    disp = _load(DispNetS.DispNetS(), _init("disp"))
+    pose = _load(PoseExpNet_sfm.PoseExpNet(nb_ref_imgs=nb_ref, output_exp=True), _init("pose", *pargs))
     disp.train(); pose.train()
     opt = FlatAdam(list(disp.parameters()) + list(pose.parameters()), lr=2e-4)
     for it in range(2):
-        loss, terms = train_sfm_losses(disp, pose, batch)
+        loss, terms = train_sfm_losses(disp, pose, batch, w2=w2)
         opt.zero_grad()
         loss.backward()
         if it == 0:
             _check_digest(g, {k: p.grad for k, p in disp.named_parameters() if p.grad is not None}, "g_disp_")
             _check_digest(g, {k: p.grad for k, p in pose.named_parameters() if p.grad is not None}, "g_pose_")
         opt.step()
-        for k in ("photo", "smooth", "lr", "total"):
+        for k in ("photo", "smooth", "lr", "total") + (("exp",) if w2 > 0 else ()):
             assert rel_err(terms[k], g[f"{k}{it}"]) < TOL, k
-    _check_params(g, "disp", disp, 2e-4)
-    _check_params(g, "pose", pose, 2e-4)
+    _check_params(g, "disp", disp, _init("disp"), 2e-4)
+    _check_params(g, "pose", pose, _init("pose", *pargs), 2e-4)
 
 
 def test_graphed_step_matches_eager():
@@ -222,9 +239,9 @@ def test_step_unsupervise_feat_golden():
         opt.step()
         for k in ("img", "smooth", "feat", "total"):
             assert rel_err(terms[k], g[f"{k}{it}"]) < TOL, k
-    _check_params(g, "disp", disp, 1e-3)
-    _check_params(g, "pose", pose, 1e-3)
-    _check_params(g, "feat", feat, 1e-3)
+    _check_params(g, "disp", disp, _init("disp"), 1e-3)
+    _check_params(g, "pose", pose, _init("pose", 6, 6, 2, True), 1e-3)
+    _check_params(g, "feat", feat, _init("feat"), 1e-3)
 
 
 def test_step_unsupervise_dvo_vs_oracle():
