@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvf_hip.so")
+# (DVF_LIB: tools/ load the -DDVF_TUNING build, libdvf_hip_tuning.so, through this; the product path never sets it)
+LIB_PATH = os.environ.get("DVF_LIB") or os.path.join(_HERE, "libdvf_hip.so")
 _lib = None
 
 c_fp = ctypes.c_void_p          # device pointer to float
@@ -50,9 +51,10 @@ SIGNATURES = {
     "dvf_pixel2cam_bwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_fp]),
     "dvf_cam2pixel_fwd": (c_i, [c_fp] * 4 + [c_i] * 3 + [c_u32, c_fp]),
     "dvf_cam2pixel_bwd": (c_i, [c_fp] * 6 + [c_i] * 3 + [c_u32, c_fp]),
-    "dvf_photo_loss_fwd": (c_i, [c_fp, c_pp, c_i] + [c_fp] * 8 + [c_i] * 4 + [c_u32, c_fp]),
+    "dvf_photo_loss_fwd": (c_i, [c_fp, c_pp, c_i] + [c_fp] * 8 + [c_i] * 4 + [c_f, c_u32, c_fp]),
     "dvf_photo_partials_floats": (c_i64, [c_i] * 4),
-    "dvf_photo_loss_bwd": (c_i, [c_fp, c_pp, c_i] + [c_fp] * 9 + [c_pp, c_fp, c_fp] + [c_i] * 4 + [c_u32, c_fp]),
+    "dvf_photo_pose_ws_floats": (c_i64, [c_i] * 4),
+    "dvf_photo_loss_bwd": (c_i, [c_fp, c_pp, c_i] + [c_fp] * 9 + [c_pp, c_fp, c_fp] + [c_i] * 4 + [c_f, c_u32, c_fp]),
     "dvf_smooth_loss_fwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_f, c_i, c_fp]),
     "dvf_smooth_partials_floats": (c_i64, [c_i] * 3),
     "dvf_smooth_loss_bwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_f, c_fp]),

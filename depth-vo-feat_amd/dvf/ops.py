@@ -47,10 +47,13 @@ class PhotoLossFn(torch.autograd.Function):
     """Fused warp + exact-zero mask + (explainability mask) + L1 mean for all views of one scale.
 
     Inputs: tgt [B,C,H,W], depth [B,H,W], pose [V,B,6], K, Kinv [B,3,3], mask [B,V,H,W] or None,
-    flags, then the V source tensors.  Output: 0-dim loss (sum over views)."""
+    flags (int, or (int, in_scale): every image value is used as in_scale * x, the `0.004 * img` of
+    unsupervise.py:101 without materialising scaled copies), then the V source tensors.
+    Output: 0-dim loss (sum over views)."""
 
     @staticmethod
     def forward(ctx, tgt, depth, pose, K, Kinv, mask, flags, *srcs):
+        flags, in_scale = flags if isinstance(flags, tuple) else (flags, 1.0)
         tgt, depth, pose, K, Kinv = map(_f32c, (tgt, depth, pose, K, Kinv))
         srcs = [_f32c(s) for s in srcs]
         mask = _f32c(mask) if mask is not None else None
@@ -65,10 +68,10 @@ class PhotoLossFn(torch.autograd.Function):
             L.check(lib.dvf_photo_loss_fwd(L.dev(tgt, "tgt"), L.ptr_array(srcs, "srcs"), V, L.dev(depth, "depth"),
                                            L.dev(pose, "pose"), L.dev(K, "intrinsics"), L.dev(Kinv, "intrinsics_inv"),
                                            L.dev(mask, "mask"), L.dev(out), L.dev(out[1:]), L.dev(partials),
-                                           B, C, H, W, flags, L.stream()), "dvf_photo_loss_fwd")
+                                           B, C, H, W, in_scale, flags, L.stream()), "dvf_photo_loss_fwd")
         ctx.fwd_bytes = fwd_bytes
         ctx.save_for_backward(tgt, depth, pose, K, Kinv, mask, *srcs)
-        ctx.flags = flags
+        ctx.flags, ctx.in_scale = flags, in_scale
         ctx.view_loss = out[1:]
         return out[0]
 
@@ -84,7 +87,7 @@ class PhotoLossFn(torch.autograd.Function):
         g_pose = torch.empty_like(pose) if need[2] else None
         g_mask = torch.empty_like(mask) if (mask is not None and need[5]) else None
         g_srcs = [torch.zeros_like(s) if need[7 + i] else None for i, s in enumerate(srcs)]
-        ws = torch.empty(int(lib.dvf_pose_ws_floats(V, B)), device=tgt.device) if need[2] else None
+        ws = torch.empty(int(lib.dvf_photo_pose_ws_floats(B, H, W, V)), device=tgt.device) if need[2] else None
         gl = _f32c(gloss).reshape(1)
         # bwd = fwd (recompute) + grad depth + mask grads + grad target + RMW scatter into the source grads
         bwd_bytes = ctx.fwd_bytes + float(B * H * W) * (
@@ -94,7 +97,7 @@ class PhotoLossFn(torch.autograd.Function):
             L.check(lib.dvf_photo_loss_bwd(L.dev(tgt), L.ptr_array(srcs), V, L.dev(depth), L.dev(pose), L.dev(K),
                                            L.dev(Kinv), L.dev(mask), L.dev(gl, "grad_loss"), L.dev(g_depth),
                                            L.dev(g_pose), L.dev(g_tgt), L.ptr_array(g_srcs), L.dev(g_mask), L.dev(ws),
-                                           B, C, H, W, ctx.flags, L.stream()), "dvf_photo_loss_bwd")
+                                           B, C, H, W, ctx.in_scale, ctx.flags, L.stream()), "dvf_photo_loss_bwd")
         return (g_tgt, g_depth, g_pose, None, None, g_mask, None, *g_srcs)
 
 

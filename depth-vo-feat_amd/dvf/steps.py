@@ -46,8 +46,8 @@ def unsupervise_losses(depth_net, pose_net, batch, feat_extractor=None, img_scal
     (_, T_2to1), disps = _side_by_side(lambda: pose_net((R2, R1)), lambda: depth_net(R2))
     inv_depth = disps[0]
     depth = reciprocal(inv_depth, depth_eps).squeeze(1)            # :99
-    img_loss = LF.photometric_reconstruction_loss(img_scale * R2, img_scale * R1, img_scale * L2, depth, T_2to1,
-                                                  batch["T_R2L"], batch["K"], batch["Kinv"])       # :101
+    img_loss = LF.photometric_reconstruction_loss(R2, R1, L2, depth, T_2to1, batch["T_R2L"], batch["K"], batch["Kinv"],
+                                                  img_scale=img_scale)   # :101 (0.004 * img applied inside the kernel)
     smooth = LF.smooth_loss(depth.unsqueeze(1))                    # :102
     terms = {"img": img_loss.detach(), "smooth": smooth.detach()}
     loss = img_loss + smooth_weight * smooth
@@ -95,8 +95,8 @@ def unsupervise_dvo_losses(depth_net, pose_net, batch, img_scale=0.004, smooth_w
     inv_depth = disps[0]
     depth = reciprocal(inv_depth, depth_eps)                               # [B,1,H,W]
     pose = torch.stack((batch["T_R2L"], T_2to1), dim=0)                    # [V=2,B,6]: view 0 = left image, view 1 = R1
-    photo = PhotoLossFn.apply(img_scale * R2, depth.squeeze(1), pose, batch["K"], batch["Kinv"], None,
-                              L.POSE_SE3 | L.PIXEL_COORDS, img_scale * L2, img_scale * R1)
+    photo = PhotoLossFn.apply(R2, depth.squeeze(1), pose, batch["K"], batch["Kinv"], None,
+                              (L.POSE_SE3 | L.PIXEL_COORDS, float(img_scale)), L2, R1)
     smooth = LF.smooth_loss(depth)
     loss = photo + smooth_weight * smooth
     return loss, {"photo": photo.detach(), "smooth": smooth.detach(), "total": loss.detach()}

@@ -98,25 +98,32 @@ int dvf_cam2pixel_bwd(const float *cam, const float *rot, const float *tr, const
  * Replaces the body of loss_functions.photometric_reconstruction_loss (loss_functions.py:7-20) and of
  * one_scale() in loss_functions_sfm.photometric_reconstruction_loss (loss_functions_sfm.py:10-36):
  * for every view v: warp src_v with pose_v, exact-zero mask, optional explainability mask, |.|, mean
- * over B*C*H*W; the views are summed.  One kernel per pyramid scale handles all V views of a pixel.
+ * over B*C*H*W; the views are summed.  One kernel per pyramid scale handles all V views of a pixel; the 2x2
+ * source neighbourhoods of a 64x4 target tile are staged through an LDS footprint tile.
  *   tgt [B,C,H,W]; srcs: HOST array of V device pointers, each [B,C,H,W]; depth [B,H,W];
  *   pose [V,B,6]; K/Kinv [B,3,3]; mask NULL or [B,V,H,W];
+ *   in_scale: every tgt / src value is used as fl(in_scale * x) -- the `0.004 * img` of unsupervise.py:101 without
+ *     materialising scaled copies (1.0f = the reference signature; must not be 0);
  *   loss_out: 1 float (sum over views), view_loss: NULL or V floats;
  *   partials: workspace >= dvf_photo_partials_floats(B,H,W,V) floats. */
 int dvf_photo_loss_fwd(const float *tgt, const float *const *srcs, int V, const float *depth,
                        const float *pose, const float *K, const float *Kinv, const float *mask,
                        float *loss_out, float *view_loss, float *partials, int B, int C, int H, int W,
-                       uint32_t flags, void *stream);
+                       float in_scale, uint32_t flags, void *stream);
 int64_t dvf_photo_partials_floats(int B, int H, int W, int V);
 /* Backward: grad_loss is a DEVICE scalar (upstream gradient).  Outputs (each may be NULL):
  *   g_depth [B,H,W] (written), g_pose [V,B,6] (written), g_tgt [B,C,H,W] (written),
- *   g_srcs: HOST array of V device pointers or NULL entries, each [B,C,H,W], ZEROED by the caller,
- *   g_mask [B,V,H,W] (written).  pose_ws >= dvf_pose_ws_floats(V,B). */
+ *   g_srcs: HOST array of V device pointers or NULL entries, each [B,C,H,W], ZEROED by the caller
+ *   (scatter-add target: accumulated per block in LDS, flushed with row-contiguous atomics),
+ *   g_mask [B,V,H,W] (written).  pose_ws >= dvf_photo_pose_ws_floats(B,H,W,V) floats (per-block [R|t] partials,
+ *   summed in fixed order: the pose gradient is bit-reproducible).  g_tgt / g_srcs need C <= 32
+ *   (DVF_ERR_UNSUPPORTED otherwise; the reference's feature maps have 32 channels, feat_extractor.py:13-36). */
 int dvf_photo_loss_bwd(const float *tgt, const float *const *srcs, int V, const float *depth,
                        const float *pose, const float *K, const float *Kinv, const float *mask,
                        const float *grad_loss, float *g_depth, float *g_pose, float *g_tgt,
                        float *const *g_srcs, float *g_mask, float *pose_ws, int B, int C, int H, int W,
-                       uint32_t flags, void *stream);
+                       float in_scale, uint32_t flags, void *stream);
+int64_t dvf_photo_pose_ws_floats(int B, int H, int W, int V);
 
 /* ---------------------------------------------------------------- smoothness loss
  * Replaces one map of smooth_loss (loss_functions.py:23-41 ; loss_functions_sfm.py:59-77):

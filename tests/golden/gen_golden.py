@@ -286,6 +286,9 @@ def gen_steps():
             k, s, n, ds, dn = param_digest(net.state_dict(), init[name])
             rec[f"p_{name}_keys"], rec[f"p_{name}_sums"], rec[f"p_{name}_norms"] = k, s, n
             rec[f"p_{name}_dsums"], rec[f"p_{name}_dnorms"] = ds, dn
+            for key, val in net.state_dict().items():         # small tensors in full: compared element by element
+                if val.numel() <= 4096:
+                    rec[f"p_{name}_val_{key}"] = _np(val)
         save("step_unsup_feat" if with_feat else "step_unsup", **rec, b=b, h=h, w=w)
 
     # ---- train.py-style (sfm; cfg 4/5 family): the base case, with the explainability term (w2 > 0, train.py:195),
@@ -328,6 +331,9 @@ def gen_steps():
             k, s, n, ds, dn = param_digest(net.state_dict(), init[name])
             rec[f"p_{name}_keys"], rec[f"p_{name}_sums"], rec[f"p_{name}_norms"] = k, s, n
             rec[f"p_{name}_dsums"], rec[f"p_{name}_dnorms"] = ds, dn
+            for key, val in net.state_dict().items():         # small tensors in full: compared element by element
+                if val.numel() <= 4096:
+                    rec[f"p_{name}_val_{key}"] = _np(val)
         save(tag, **rec, b=bb, h=h, w=w, nb_ref=nb_ref, w2=w2)
 
 

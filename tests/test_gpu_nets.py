@@ -71,19 +71,28 @@ def test_posenet_golden(tag):
 
 
 def _check_params(g, name, module, sd0, lr, n_steps=2):
-    """Post-Adam parameters vs the reference run (see tests/test_oracle_golden.py::_check_params): norm at 1e-4, and
-    the UPDATE p - p0 by norm (1e-3) and by sum (1e-3 of its norm + 2*lr*n_steps*(2 + 1e-5*numel) for sign flips of
+    """Post-Adam parameters vs the reference run (see tests/test_oracle_golden.py::_check_params): small tensors
+    element by element, large ones by norm at 1e-4, and
+    the UPDATE p - p0 by norm (1e-3) and by sum (1e-3 of its norm + 2*lr*n_steps*(4 + 1e-4*numel) for sign flips of
     noise-level gradients)."""
     sd = {k: v.detach().double().cpu() for k, v in module.state_dict().items()}
     keys = [str(k) for k in g[f"p_{name}_keys"]]
     assert sorted(sd) == keys
     for i, k in enumerate(keys):
         n = float(g[f"p_{name}_norms"][i])
+        if f"p_{name}_val_{k}" in g:
+            # small tensors (<= 4096 elements; one element is up to 2% of a bias' norm): element by element against
+            # the reference's values at 1e-5 absolute (0.5% of one Adam step) -- except that an element whose gradient
+            # is at rounding-noise level may step the other way (2*lr per step): at most 1 + 2% of the elements
+            dev = (sd[k].double().cpu() - torch.from_numpy(g[f"p_{name}_val_{k}"]).double()).abs()
+            assert float(dev.max()) <= 2 * lr * n_steps * 1.01, (k, float(dev.max()))
+            assert int((dev > 1e-5).sum()) <= 1 + 0.02 * dev.numel(), (k, int((dev > 1e-5).sum()), dev.numel())
+            continue
         assert abs(float(sd[k].norm()) - n) / max(n, 1e-12) < TOL, k
         upd = sd[k] - sd0[k].double()
         dn, ds = float(g[f"p_{name}_dnorms"][i]), float(g[f"p_{name}_dsums"][i])
         assert abs(float(upd.norm()) - dn) <= 1e-3 * dn, (k, float(upd.norm()), dn)
-        flip = 2 * lr * n_steps * (2 + 1e-5 * upd.numel())
+        flip = 2 * lr * n_steps * (4 + 1e-4 * upd.numel())
         assert abs(float(upd.sum()) - ds) <= 1e-3 * dn + flip, (k, float(upd.sum()), ds)
 
 
@@ -163,45 +172,64 @@ def test_step_train_sfm_golden(name):
     _check_params(g, "pose", pose, _init("pose", *pargs), 2e-4)
 
 
-def test_graphed_step_matches_eager():
-    """The HIP-graph replay of a whole step is equivalent to eager execution.  Two EAGER runs already differ (float
-    atomics in wgrad / split-K / pose partials change summation order, and Adam's first steps move an element by
-    lr*g/(|g|+eps), which is O(lr)-sensitive where |g| ~ eps), so the graph run is held to 5x the eager-vs-eager
-    spread (two samples of it), with every element inside the hard bound of 2*lr per step."""
+def test_streams_and_graph_match_serial():
+    """Forward + backward of the cfg-2 step body three ways -- every kernel on ONE stream (DVF_SERIALIZE semantics),
+    the production three-stream schedule (pose network on the auxiliary stream, weight gradients on side streams), and
+    a HIP-graph replay of that schedule -- must leave the same gradient arena.  Nothing but summation order may differ
+    (float atomics in wgrad / bias-gradient accumulation; the loss and pose-gradient reductions are deterministic), so
+    every parameter's gradient is held to 1e-5 (norm of the difference / norm): a missing stream dependency or a stale
+    buffer in the captured graph is orders of magnitude above that.  No optimizer step is taken, so no Adam
+    amplification enters.  The serial variant is also run twice to show the run-to-run floor."""
     import DispNetS
     import PoseExpNet
+    from dvf import lib as L
     from dvf.engine import FlatAdam, GraphedStep
     from dvf.steps import unsupervise_losses
-    b, h, w = 1, 64, 128
+    b, h, w = 2, 128, 416
     batch = _batch(b, h, w)
-    results = []
-    for mode in ("eager", "eager", "graph"):
-        disp = _load(DispNetS.DispNetS(), onets.fill_params(onets.dispnet_layers(), seed=1))
-        pose = _load(PoseExpNet.PoseExpNet(output_exp=True), onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2))
-        opt = FlatAdam(list(pose.parameters()) + list(disp.parameters()), lr=1e-3, weight_decay=1e-8)
+    arenas = {}
+    for mode in ("serial", "serial2", "eager", "graph"):
+        L.SERIALIZE = mode.startswith("serial")
+        try:
+            disp = _load(DispNetS.DispNetS(), _init("disp"))
+            pose = _load(PoseExpNet.PoseExpNet(output_exp=True), _init("pose", 6, 6, 2, True))
+            disp.train(); pose.train()
+            opt = FlatAdam(list(pose.parameters()) + list(disp.parameters()), lr=1e-3, weight_decay=1e-8)
 
-        def step():
-            loss, terms = unsupervise_losses(disp, pose, batch)
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
-            return (terms["total"],)
+            def fwd_bwd():
+                loss, terms = unsupervise_losses(disp, pose, batch)
+                opt.zero_grad()
+                loss.backward()
+                opt.join_wgrad()
+                L.join_aux_streams()
+                return (terms["total"],)
 
-        if mode == "graph":
-            runner = GraphedStep(step, [], warmup=2)       # 2 eager steps, then capture (enqueues nothing)
-            losses = [float(runner()[0]) for _ in range(2)]  # replays = steps 3 and 4
-        else:
-            losses = [float(step()[0]) for _ in range(4)][2:]
-        torch.cuda.synchronize()
-        results.append((losses, opt.flat_p.clone()))
-    (l0, p0), (l1, p1), (l2, p2) = results
-    spread_l = max(abs(a - b) / abs(a) for a, b in zip(l0, l1))
-    spread_p = float((p1 - p0).norm() / p0.norm())
-    # (one eager pair is a noisy estimate of the run-to-run spread -- three streams reorder the float atomics -- hence the
-    # 5e-3 floor (a stale-weight bug shows up as 0.6); exact parity of a step is what the golden step tests above check)
-    assert max(abs(a - b) / abs(a) for a, b in zip(l0, l2)) <= max(5e-3, 5 * spread_l)
-    assert float((p2 - p0).abs().max()) <= 2 * 1e-3 * 4
-    assert float((p2 - p0).norm() / p0.norm()) <= max(5e-3, 5 * spread_p)
+            if mode == "graph":
+                runner = GraphedStep(fwd_bwd, [], warmup=2)
+                runner()
+                loss = runner()[0]
+            else:
+                fwd_bwd()
+                loss = fwd_bwd()[0]
+            torch.cuda.synchronize()
+            arenas[mode] = (float(loss), opt.flat_g.clone(), [(o, p.numel()) for o, p in zip(opt.offsets, opt.params)])
+        finally:
+            L.SERIALIZE = False
+    l0, g0, views = arenas["serial"]
+    worst = {}
+    for mode in ("serial2", "eager", "graph"):
+        l1, g1, _ = arenas[mode]
+        assert abs(l1 - l0) <= 1e-6 * abs(l0), (mode, l0, l1)          # the loss path has no atomics at all
+        w = 0.0
+        for o, n in views:
+            ref = g0[o:o + n].double()
+            rn = float(ref.norm())
+            if rn > 0:
+                w = max(w, float((g1[o:o + n].double() - ref).norm()) / rn)
+        worst[mode] = w
+    print("gradient arena vs serial: %s" % worst)
+    for mode, w in worst.items():
+        assert w <= 1e-5, worst
 
 
 def test_featnet_golden():

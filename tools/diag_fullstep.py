@@ -8,7 +8,7 @@ import DispNetS, PoseExpNet
 from dvf.steps import unsupervise_losses
 from dvf.synthetic import synthetic_batch
 from dvf import lib as L
-B, H, W = int(os.environ.get("B", 4)), 256, 832
+B, H, W = int(os.environ.get("B", 4)), int(os.environ.get("H", 256)), int(os.environ.get("W", 832))
 if os.environ.get("SER"): L.SERIALIZE = True
 dsd = onets.fill_params(onets.dispnet_layers(), seed=1)
 psd = onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2)
@@ -23,7 +23,7 @@ R2, R1, L2 = batch["img_R2"], batch["img_R1"], batch["img_L2"]
 _, T21 = pose((R2, R1))
 d0 = disp(R2)[0]; d0.retain_grad(); T21.retain_grad()
 depth = reciprocal(d0, 1e-4).squeeze(1)
-il = LF.photometric_reconstruction_loss(0.004 * R2, 0.004 * R1, 0.004 * L2, depth, T21, batch["T_R2L"], batch["K"], batch["Kinv"])
+il = LF.photometric_reconstruction_loss(R2, R1, L2, depth, T21, batch["T_R2L"], batch["K"], batch["Kinv"], img_scale=0.004) if not os.environ.get("PRESCALE") else LF.photometric_reconstruction_loss(0.004 * R2, 0.004 * R1, 0.004 * L2, depth, T21, batch["T_R2L"], batch["K"], batch["Kinv"])
 sm = LF.smooth_loss(depth.unsqueeze(1))
 (il + 10 * sm).backward()
 torch.cuda.synchronize()
