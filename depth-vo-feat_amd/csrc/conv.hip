@@ -47,7 +47,8 @@ struct GatherArgs {
     ClassDev cls[4];
     int act;
     float alpha, beta;
-    int KS, NCH, atomic_out, dbg;
+    int KS, NCH, atomic_out, dbg;        // atomic_out 0: bias+act store, 1: atomicAdd into a zeroed output, 2: plain partial store at ks*ws_slice
+    int64_t ws_slice;
     int lsw, lsh, TGX, BW, BH, tilesX, tilesY;
     int PSmax, Tmax, WD; // LDS carve: patch CK*PSmax | weights Tmax*CK*COTP | wdec WD | tapB Tmax | inv 64
     int tapmap[52];      // class c uses tapmap[cls[c].tap0 + t]: class tap -> tap index of the stored kernel
@@ -289,6 +290,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
                     if (!a.atomic_out) {
                         if (a.bias) v += a.bias[mm];
                         *op = apply_act(v, a.act, a.alpha, a.beta);
+                    } else if (a.atomic_out == 2) {
+                        op[(int64_t)ks * a.ws_slice] = v;
                     } else {
                         atomicAdd(op, v);
                     }
@@ -784,24 +787,45 @@ int launch_gather_ck(const GatherArgs &a, const GatherPlan &pl, hipStream_t st) 
 // Run the classes of one op in ONE launch.  With split-K (or classes that do not cover every output pixel) the
 // blocks accumulate with atomics into a zeroed output and bias + activation are applied by one finishing pass;
 // otherwise they are fused in the epilogue.
-int run_classes(const GatherArgs &base, const ClassSpec *cls, int ncls, bool covers_all, hipStream_t st) {
+int run_classes(const GatherArgs &base, const ClassSpec *cls, int ncls, bool covers_all, hipStream_t st,
+                float *ws = nullptr, int64_t ws_floats = 0, int64_t *ws_need = nullptr);
+
+// splitk_reduce_kernel is defined in conv_pipe_host.h (included below)
+__global__ void splitk_reduce_kernel(const float *ws, float *out, const float *bias, int KS, int64_t slice, int C, int64_t HW,
+                                     int act, float alpha, float beta);
+
+int run_classes(const GatherArgs &base, const ClassSpec *cls, int ncls, bool covers_all, hipStream_t st, float *ws,
+                int64_t ws_floats, int64_t *ws_need) {
     GatherArgs a = base;
     GatherPlan pl;
     int rc = plan_gather(a, cls, ncls, pl);
     if (rc) return rc;
     const bool split = !covers_all || a.KS > 1;
     const int64_t HW = (int64_t)a.OH * a.OW, total = (int64_t)a.N * a.M * HW;
-    if (split && hipMemsetAsync(a.out, 0, sizeof(float) * total, st) != hipSuccess) return DVF_ERR_LAUNCH;
-    a.atomic_out = split ? 1 : 0;
+    // split-K over a covering class set: with a workspace the K-splits store plain partial tiles that one pass reduces in
+    // fixed order (+bias, activation) -- deterministic; without it they accumulate with float atomics into a zeroed output
+    const int64_t need = (covers_all && a.KS > 1) ? (int64_t)a.KS * total : 0;
+    if (ws_need) { *ws_need = need; return DVF_OK; }       // size query only
+    const bool use_ws = need > 0 && ws && ws_floats >= need;
+    float *out = a.out;
+    if (use_ws) { a.out = ws; a.ws_slice = total; a.atomic_out = 2; }
+    else {
+        if (split && hipMemsetAsync(a.out, 0, sizeof(float) * total, st) != hipSuccess) return DVF_ERR_LAUNCH;
+        a.atomic_out = split ? 1 : 0;
+    }
     if (pl.MT == 2 && pl.NT == 2) rc = launch_gather_ck<2, 2>(a, pl, st);
     else if (pl.MT == 2) rc = launch_gather_ck<2, 1>(a, pl, st);
     else if (pl.NT == 2) rc = launch_gather_ck<1, 2>(a, pl, st);
     else rc = launch_gather_ck<1, 1>(a, pl, st);
     if (rc) return rc;
-    dvf_plan_note(DVF_K_GATHER, pl.MT, pl.NT, 1, 2 * pl.CKH, 0, a.KS, 1, 1, 256, (int)pl.lds, (split ? 1 : 0) | (a.ncls << 4));
-    if (split && (a.bias || a.act != DVF_ACT_NONE)) {
-        const int64_t nb = (total + 255) / 256;
-        bias_act_kernel<<<(int)(nb > 2048 ? 2048 : nb), 256, 0, st>>>(a.out, a.bias, a.M, HW, total, a.act, a.alpha,
+    dvf_plan_note(DVF_K_GATHER, pl.MT, pl.NT, 1, 2 * pl.CKH, 0, a.KS, 1, 1, 256, (int)pl.lds, a.atomic_out | (a.ncls << 4));
+    const int64_t nb = (total + 255) / 256;
+    if (use_ws) {
+        splitk_reduce_kernel<<<(int)(nb > 4096 ? 4096 : nb), 256, 0, st>>>(ws, out, a.bias, a.KS, total, a.M, HW, a.act, a.alpha,
+                                                                          a.beta);
+        DVF_LAUNCH_CHECK();
+    } else if (split && (a.bias || a.act != DVF_ACT_NONE)) {
+        bias_act_kernel<<<(int)(nb > 2048 ? 2048 : nb), 256, 0, st>>>(out, a.bias, a.M, HW, total, a.act, a.alpha,
                                                                      a.beta);
         DVF_LAUNCH_CHECK();
     }
@@ -909,27 +933,33 @@ int make_dgrad_op(const dvf_conv_desc *d, const float *dpre, float *din, int off
 
 extern "C" {
 
-int dvf_conv2d_fwd(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
-                   const float *w, const float *bias, float *out, void *stream) {
-    dvf_plan_reset();
+}  // extern "C"
+
+namespace {
+// Forward through the unpacked kernels.  ws_need != nullptr: only report the split-K workspace the call would use.
+int fwd_unpacked(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg, const float *w,
+                 const float *bias, float *out, float *ws, int64_t ws_floats, int64_t *ws_need, void *stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     rc = check_segs(d, seg_channels, nseg);
     if (rc) return rc;
-    if (!in_segs || !w || !out) return DVF_ERR_INVALID_ARG;
+    if (!ws_need && (!in_segs || !w || !out)) return DVF_ERR_INVALID_ARG;
+    if (ws_need) *ws_need = 0;
     if (dvf_head_applicable(d, nseg)) {
+        if (ws_need) return DVF_OK;
         if (!in_segs[0]) return DVF_ERR_INVALID_ARG;
         return dvf_head_fwd(d, in_segs[0], w, bias, out, dvf_stream(stream));
     }
     if (dvf_head_wide_applicable(d, nseg)) {
+        if (ws_need) return DVF_OK;
         for (int s = 0; s < nseg; ++s)
             if (!in_segs[s]) return DVF_ERR_INVALID_ARG;
         return dvf_head_fwd_segs(d, in_segs, seg_channels, nseg, w, bias, out, dvf_stream(stream));
     }
     GatherArgs a{};
     for (int s = 0; s < nseg; ++s) {
-        if (!in_segs[s]) return DVF_ERR_INVALID_ARG;
-        a.in[s] = in_segs[s];
+        if (!ws_need && !in_segs[s]) return DVF_ERR_INVALID_ARG;
+        a.in[s] = ws_need ? nullptr : in_segs[s];
         a.segC[s] = seg_channels[s];
     }
     a.nseg = nseg; a.w = w; a.KK = d->KH * d->KW; a.m_base = 0; a.M = d->C_out; a.bias = bias; a.out = out;
@@ -942,13 +972,27 @@ int dvf_conv2d_fwd(const dvf_conv_desc *d, const float *const *in_segs, const in
         a.w_mode = 0;
         cls[0] = ClassSpec{1, 0, 0, d->stride, -d->pad, -d->pad, d->KH, d->KW, d->H_out, d->W_out, {0}};
         for (int t = 0; t < a.KK; ++t) cls[0].tapmap[t] = t;
-        return run_classes(a, cls, 1, true, dvf_stream(stream));
+        return run_classes(a, cls, 1, true, dvf_stream(stream), ws, ws_floats, ws_need);
     }
     // out[co][Y][X] = sum_ci sum_ab W[ci][co][a][b] * in[ci][i][j],  Y = i*s - p + a   (one launch per parity)
     a.w_mode = 1;
     bool covers;
     const int ncls = scatter_classes(d->stride, d->pad, d->KH, d->KW, d->H_out, d->W_out, cls, &covers);
-    return run_classes(a, cls, ncls, covers, dvf_stream(stream));
+    return run_classes(a, cls, ncls, covers, dvf_stream(stream), ws, ws_floats, ws_need);
+}
+}  // namespace
+
+extern "C" {
+
+int dvf_conv2d_fwd_ws(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                      const float *w, const float *bias, float *out, float *ws, int64_t ws_floats, void *stream) {
+    dvf_plan_reset();
+    return fwd_unpacked(d, in_segs, seg_channels, nseg, w, bias, out, ws, ws_floats, nullptr, stream);
+}
+
+int dvf_conv2d_fwd(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                   const float *w, const float *bias, float *out, void *stream) {
+    return dvf_conv2d_fwd_ws(d, in_segs, seg_channels, nseg, w, bias, out, nullptr, 0, stream);
 }
 
 }  // extern "C"
@@ -956,8 +1000,9 @@ int dvf_conv2d_fwd(const dvf_conv_desc *d, const float *const *in_segs, const in
 namespace {
 // dgrad of one input segment with the unpacked weights: the head kernel for narrow segments, else conv_gather_kernel
 int dgrad_segment_unpacked(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int off, int segc,
-                           hipStream_t st) {
-    if (dvf_head_seg_dgrad_applicable(d, segc)) return dvf_head_seg_dgrad(d, dpre, w, din, off, segc, st);
+                           hipStream_t st, float *ws = nullptr, int64_t ws_floats = 0, int64_t *ws_need = nullptr) {
+    if (ws_need) *ws_need = 0;
+    if (dvf_head_seg_dgrad_applicable(d, segc)) return ws_need ? DVF_OK : dvf_head_seg_dgrad(d, dpre, w, din, off, segc, st);
     GatherArgs a{};
     a.in[0] = dpre; a.segC[0] = d->C_out; a.nseg = 1;
     a.w = w; a.KK = d->KH * d->KW; a.m_base = off; a.M = segc; a.bias = nullptr; a.out = din;
@@ -970,20 +1015,20 @@ int dgrad_segment_unpacked(const dvf_conv_desc *d, const float *dpre, const floa
         a.w_mode = 1;
         bool covers;
         const int ncls = scatter_classes(d->stride, d->pad, d->KH, d->KW, d->H_in, d->W_in, cls, &covers);
-        return run_classes(a, cls, ncls, covers, st);
+        return run_classes(a, cls, ncls, covers, st, ws, ws_floats, ws_need);
     }
     // din[ci][i][j] = sum_co sum_ab W[ci][co][a][b] * dpre[co][i*s - p + a][j*s - p + b]
     a.w_mode = 0;
     cls[0] = ClassSpec{1, 0, 0, d->stride, -d->pad, -d->pad, d->KH, d->KW, d->H_in, d->W_in, {0}};
     for (int t = 0; t < a.KK; ++t) cls[0].tapmap[t] = t;
-    return run_classes(a, cls, 1, true, st);
+    return run_classes(a, cls, 1, true, st, ws, ws_floats, ws_need);
 }
 }  // namespace
 
 extern "C" {
 
-int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *const *din_segs,
-                     const int *seg_channels, int nseg, void *stream) {
+int dvf_conv2d_dgrad_ws(const dvf_conv_desc *d, const float *dpre, const float *w, float *const *din_segs,
+                        const int *seg_channels, int nseg, float *ws, int64_t ws_floats, void *stream) {
     dvf_plan_reset();
     int rc = check_desc(d);
     if (rc) return rc;
@@ -995,12 +1040,17 @@ int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, 
     for (int s = 0; s < nseg; ++s) {
         const int segc = seg_channels[s];
         if (din_segs[s]) {
-            rc = dgrad_segment_unpacked(d, dpre, w, din_segs[s], off, segc, dvf_stream(stream));
+            rc = dgrad_segment_unpacked(d, dpre, w, din_segs[s], off, segc, dvf_stream(stream), ws, ws_floats);
             if (rc) return rc;
         }
         off += segc;
     }
     return DVF_OK;
+}
+
+int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *const *din_segs,
+                     const int *seg_channels, int nseg, void *stream) {
+    return dvf_conv2d_dgrad_ws(d, dpre, w, din_segs, seg_channels, nseg, nullptr, 0, stream);
 }
 
 int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
@@ -1157,6 +1207,11 @@ int64_t pipe_sizes(const dvf_conv_desc *d, const int *seg_channels, int nseg, in
         rc = make_fwd_op(d, nullptr, seg_channels, nseg, nullptr, nullptr, op);
         if (rc) return rc;
         rc = pipe_pack(op, nullptr, nullptr, &nf, &wf, nullptr);
+        if (rc == DVF_ERR_UNSUPPORTED && want_ws) {            // unpacked kernels: their split-K scratch
+            int64_t need = 0;
+            rc = fwd_unpacked(d, nullptr, seg_channels, nseg, nullptr, nullptr, nullptr, nullptr, 0, &need, nullptr);
+            return rc ? rc : need;
+        }
         return rc ? rc : (want_ws ? wf : nf);
     }
     if (op_kind != 1) return DVF_ERR_INVALID_ARG;
@@ -1170,10 +1225,15 @@ int64_t pipe_sizes(const dvf_conv_desc *d, const int *seg_channels, int nseg, in
             total += nf;
             wmax = wf > wmax ? wf : wmax;
             ++nsup;
+        } else if (want_ws) {
+            int64_t need = 0;
+            rc = dgrad_segment_unpacked(d, nullptr, nullptr, nullptr, off, seg_channels[s], nullptr, nullptr, 0, &need);
+            if (rc) return rc;
+            wmax = need > wmax ? need : wmax;
         }
         off += seg_channels[s];
     }
-    if (!nsup) return DVF_ERR_UNSUPPORTED;
+    if (!nsup && !want_ws) return DVF_ERR_UNSUPPORTED;
     return want_ws ? wmax : total;
 }
 
@@ -1252,7 +1312,7 @@ int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const flo
         if (rc == DVF_ERR_UNSUPPORTED) {                                  // narrow segment: unpacked kernels
             if (din_segs[s]) {
                 if (!w) return DVF_ERR_INVALID_ARG;
-                rc = dgrad_segment_unpacked(d, dpre, w, din_segs[s], off, seg_channels[s], dvf_stream(stream));
+                rc = dgrad_segment_unpacked(d, dpre, w, din_segs[s], off, seg_channels[s], dvf_stream(stream), ws, ws_floats);
                 if (rc) return rc;
             }
         } else {

@@ -7,8 +7,13 @@
 //   * forward / backward pass 1: the footprint of PT_CC channels is STAGED IN LDS with coalesced 16-byte row loads and
 //     every pixel reads its four taps from LDS (no per-pixel gathers from HBM);
 //   * backward pass 2 (source gradients, the feature-reconstruction loss): the scatter-add of the four tap weights is
-//     ACCUMULATED IN THE SAME LDS TILE (ds_add_f32) and flushed once per footprint element with row-contiguous global
-//     atomics -- four global atomics per (pixel, channel, view) become ~1.3, in 256-byte contiguous shapes.
+//     ACCUMULATED IN THE SAME LDS TILE and flushed once per footprint element with row-contiguous global atomics --
+//     four global atomics per (pixel, channel, view) become ~1.3, in 256-byte contiguous shapes.  The LDS accumulation
+//     is in 32-bit FIXED POINT (ds_add_u32): on gfx950 ds_add_f32 takes 192 cycles per wave-instruction (three per
+//     lane, serialised), ds_add_u32 5-8 (tools/micro/lds_atomic.hip).  Scale per (block, view): 2^22 over the power
+//     of two above the largest |upstream value| of the block, so a contribution keeps 22 significant bits of the
+//     largest one (fp32 adds keep 24 of the running sum) and the 256 pixels of a block cannot overflow 2^31; integer
+//     adds commute, so a block's accumulation is order independent.
 // A footprint that does not fit the LDS tile (wild depth inside one tile) falls back, for that (block, view) only, to
 // direct 8-byte pair gathers and direct global atomics; a footprint with no valid tap at all is skipped.
 // The loss sum and the pose-gradient partials are reduced wavefront-first and finished in fixed order by a second
@@ -22,8 +27,8 @@ namespace {
 
 using namespace dvfw;
 
-constexpr int PT_CC = 8;          // channels per staged chunk
-constexpr int PT_CAP = 1200;      // floats per channel of a footprint tile (68 x 5 typical; up to 128 x 9 / 72 x 16): 8 channels = 38.4 KB, four blocks per CU
+constexpr int PT_CC = 16;         // channels per staged chunk
+constexpr int PT_CAP = 600;       // floats per channel of a footprint tile (68 x 5 typical; up to 120 x 5 / 72 x 8): 16 channels = 38.4 KB, four blocks per CU
 constexpr int PT_MAXC = 32;       // the backward kernel keeps one L1 sign per (view, channel) in two 32-bit fields
 
 struct PhotoArgs {
@@ -39,7 +44,7 @@ struct PhotoArgs {
     uint32_t quat;
     float in_scale;
     int vec;                       // sources may be staged in 16-byte lanes (W % 4 == 0, 16-byte aligned bases)
-    int dbg;                       // ablation switches (-DDVF_TUNING builds only): 1 no pass 2, 2 no flush atomics, 4 no LDS adds, 8 no staging
+    int dbg;                       // ablation switches (-DDVF_TUNING builds only): 1 no pass 2, 2 no flush atomics, 4 no LDS adds, 8 no staging, 16 no LDS tiles at all
 };
 
 __device__ __forceinline__ void block_setup(const PhotoArgs &a, int b, int tid, ViewGeo *geo, float *kinv, float *kmat) {
@@ -81,39 +86,29 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // Footprint of the block's pixels in one source view (block-uniform).
 struct Foot { int xlo, ylo, RS, rows, mode; };       // mode 0: no valid tap, 1: LDS tile, 2: direct (does not fit)
 
-template <int NV>
-__device__ __forceinline__ void footprints(const TapPos (&tp)[NV], int W, int vec, int (*bbs)[DVF_MAX_VIEWS][4],
-                                           Foot (&ft)[NV]) {
-#pragma unroll
-    for (int vi = 0; vi < NV; ++vi) {
-        const TapPos &p = tp[vi];
-        const int mnx = wave_min_i(p.any ? p.xb : 0x7fffffff), mxx = wave_max_i(p.any ? p.xb + 1 : -1);
-        const int mny = wave_min_i(p.any ? p.y0 : 0x7fffffff), mxy = wave_max_i(p.any ? p.y1 : -1);
-        if (threadIdx.x == 0) {
-            bbs[threadIdx.y][vi][0] = mnx; bbs[threadIdx.y][vi][1] = mxx;
-            bbs[threadIdx.y][vi][2] = mny; bbs[threadIdx.y][vi][3] = mxy;
-        }
-    }
+// Block reduction of one view's tap positions to its footprint (two barriers).
+__device__ __forceinline__ Foot footprint(const TapPos &p, int vec, int (*bbs)[4], bool force_direct) {
+    const int mnx = wave_min_i(p.any ? p.xb : 0x7fffffff), mxx = wave_max_i(p.any ? p.xb + 1 : -1);
+    const int mny = wave_min_i(p.any ? p.y0 : 0x7fffffff), mxy = wave_max_i(p.any ? p.y1 : -1);
+    __syncthreads();                                        // (bbs of the previous view fully read)
+    if (threadIdx.x == 0) { bbs[threadIdx.y][0] = mnx; bbs[threadIdx.y][1] = mxx; bbs[threadIdx.y][2] = mny; bbs[threadIdx.y][3] = mxy; }
     __syncthreads();
+    int x0 = bbs[0][0], x1 = bbs[0][1], y0 = bbs[0][2], y1 = bbs[0][3];
 #pragma unroll
-    for (int vi = 0; vi < NV; ++vi) {
-        int mnx = bbs[0][vi][0], mxx = bbs[0][vi][1], mny = bbs[0][vi][2], mxy = bbs[0][vi][3];
-#pragma unroll
-        for (int w = 1; w < TY; ++w) {
-            mnx = min(mnx, bbs[w][vi][0]); mxx = max(mxx, bbs[w][vi][1]);
-            mny = min(mny, bbs[w][vi][2]); mxy = max(mxy, bbs[w][vi][3]);
-        }
-        Foot f;
-        // (readfirstlane: the values are block-uniform; keeps the staging loops' bookkeeping scalar)
-        mnx = __builtin_amdgcn_readfirstlane(mnx); mxx = __builtin_amdgcn_readfirstlane(mxx);
-        mny = __builtin_amdgcn_readfirstlane(mny); mxy = __builtin_amdgcn_readfirstlane(mxy);
-        f.xlo = vec ? (mnx & ~3) : mnx;
-        f.ylo = mny;
-        f.RS = vec ? ((mxx - f.xlo + 1 + 3) & ~3) : (mxx - f.xlo + 1);
-        f.rows = mxy - mny + 1;
-        f.mode = (mxx < 0) ? 0 : ((f.RS * f.rows <= PT_CAP && f.RS <= 256) ? 1 : 2);
-        ft[vi] = f;
+    for (int w = 1; w < TY; ++w) {
+        x0 = min(x0, bbs[w][0]); x1 = max(x1, bbs[w][1]);
+        y0 = min(y0, bbs[w][2]); y1 = max(y1, bbs[w][3]);
     }
+    // (readfirstlane: the values are block-uniform; keeps the staging loops' bookkeeping scalar)
+    x0 = __builtin_amdgcn_readfirstlane(x0); x1 = __builtin_amdgcn_readfirstlane(x1);
+    y0 = __builtin_amdgcn_readfirstlane(y0); y1 = __builtin_amdgcn_readfirstlane(y1);
+    Foot f;
+    f.xlo = vec ? (x0 & ~3) : x0;
+    f.ylo = y0;
+    f.RS = vec ? ((x1 - f.xlo + 1 + 3) & ~3) : (x1 - f.xlo + 1);
+    f.rows = y1 - y0 + 1;
+    f.mode = (x1 < 0) ? 0 : ((f.RS * f.rows <= PT_CAP && f.RS <= 256 && !force_direct) ? 1 : 2);
+    return f;
 }
 
 // idx / d for 0 <= idx < 2^16, small d, through fp32 (exact: the +0.5 keeps the quotient 0.5/d away from an integer)
@@ -196,77 +191,72 @@ __device__ __forceinline__ Taps taps_direct(const float *__restrict__ plane, con
     return taps_select(top.x, top.y, bot.x, bot.y, p);
 }
 
+// One view at a time (projection, footprint, staged chunks): only one view's sampling state is live, which keeps the
+// kernel at four waves per SIMD -- the tile pipeline is latency bound (barriers) and needs the occupancy.
 template <bool BORDER, bool ALIGN, bool PIX, int NV>
 __global__ __launch_bounds__(256) void photo_fwd_kernel(PhotoArgs a) {
     __shared__ ViewGeo geo[DVF_MAX_VIEWS];
     __shared__ float kinv[9];
     __shared__ float red[TY][DVF_MAX_VIEWS];
-    __shared__ int bbs[TY][DVF_MAX_VIEWS][4];
+    __shared__ int bbs[TY][4];
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int b = blockIdx.z, tid = threadIdx.y * TX + threadIdx.x;
     block_setup(a, b, tid, geo, kinv, nullptr);
     const int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
     const int W = a.W, H = a.H, C = a.C;
-    const int64_t HW = (int64_t)H * W;
+    const int HW = H * W;
     const bool inside = x < W && y < H;
-    const int64_t pix = (int64_t)min(y, H - 1) * W + min(x, W - 1);
+    const int pix = min(y, H - 1) * W + min(x, W - 1);
     const float d = a.depth[(int64_t)b * HW + pix];
     // cam = (Kinv @ (u, v, 1)) * depth                      inverse_warp.py:38-40
     const float u = (float)x, v = (float)y;
     const float cx = (kinv[0] * u + kinv[1] * v + kinv[2]) * d;
     const float cy = (kinv[3] * u + kinv[4] * v + kinv[5]) * d;
     const float cz = (kinv[6] * u + kinv[7] * v + kinv[8]) * d;
-    Samp s[NV];
-    TapPos tp[NV];
-    Foot ft[NV];
-    float acc[NV];
-    bool nz[NV];
+    const float *tg = a.tgt + (int64_t)b * C * HW + pix;
 #pragma unroll
     for (int vi = 0; vi < NV; ++vi) {
-        s[vi] = project<BORDER, ALIGN, PIX>(geo[vi], cx, cy, cz, W, H);
-        tp[vi] = tap_pos(s[vi], W, H, inside);
-        acc[vi] = 0.f;
-        nz[vi] = false;
-    }
-    footprints<NV>(tp, W, a.vec, bbs, ft);
-    const float *tg = a.tgt + (int64_t)b * C * HW + pix;
-    for (int c0 = 0; c0 < C; c0 += PT_CC) {
-        const int nch = min(PT_CC, C - c0);
-        float tv[PT_CC];
-#pragma unroll
-        for (int k = 0; k < PT_CC; ++k) {
-            tv[k] = (k < nch) ? tg[(int64_t)(c0 + k) * HW] : 0.f;
-            if (a.in_scale != 1.f) tv[k] = __fmul_rn(a.in_scale, tv[k]);
-        }
-#pragma unroll
-        for (int vi = 0; vi < NV; ++vi) {
-            const Foot f = ft[vi];
-            if (f.mode == 0) continue;                      // no pixel of the block samples inside this source
-            if (f.mode == 1) {
-                __syncthreads();                            // previous tile fully consumed
-                if (!DVF_DBG(a, 8)) stage_tile(tile, a.src[vi], f, b, C, c0, nch, H, W, a.in_scale, a.vec, tid);
-                __syncthreads();
-            }
-            if (!tp[vi].any) continue;                      // warped == 0 in every channel: nz stays false
-            const TileOff o = tile_off(tp[vi], f);
+        const Samp s = project<BORDER, ALIGN, PIX>(geo[vi], cx, cy, cz, W, H);
+        const TapPos tp = tap_pos(s, W, H, inside);
+        const Foot f = footprint(tp, a.vec, bbs, DVF_DBG(a, 16));
+        float acc = 0.f;
+        bool nz = false;
+        if (f.mode != 0) {                                  // (mode 0: no pixel of the block samples inside this source)
+            const TileOff o = tile_off(tp, f);
             const int chs = f.rows * f.RS;
-            const float *sp = a.src[vi] + ((int64_t)b * C + c0) * HW;
+            for (int c0 = 0; c0 < C; c0 += PT_CC) {
+                const int nch = min(PT_CC, C - c0);
+                if (f.mode == 1) {
+                    __syncthreads();                        // previous tile fully consumed
+                    if (!DVF_DBG(a, 8)) stage_tile(tile, a.src[vi], f, b, C, c0, nch, H, W, a.in_scale, a.vec, tid);
+                    __syncthreads();
+                }
+                if (!tp.any) continue;                      // warped == 0 in every channel: nz stays false
+                const float *sp = a.src[vi] + ((int64_t)b * C + c0) * HW;
+#pragma unroll 1
+                for (int k0 = 0; k0 < nch; k0 += 4) {       // four channels at a time
+                    float tv[4];
 #pragma unroll
-            for (int k = 0; k < PT_CC; ++k) {
-                if (k < nch) {
-                    const Taps t = (f.mode == 1) ? taps_lds(tile + k * chs, o, tp[vi]) : taps_direct(sp + (int64_t)k * HW, tp[vi], W, a.in_scale);
-                    const float wv = blend(t, s[vi]);
-                    nz[vi] |= (wv != 0.f);                  // loss_functions.py:11  (warped == 0).prod(1)
-                    acc[vi] += fabsf(tv[k] - wv);           // :12-13
+                    for (int j = 0; j < 4; ++j) {
+                        tv[j] = (k0 + j < nch) ? tg[(c0 + k0 + j) * HW] : 0.f;
+                        if (a.in_scale != 1.f) tv[j] = __fmul_rn(a.in_scale, tv[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (k0 + j < nch) {
+                            const Taps t = (f.mode == 1) ? taps_lds(tile + (k0 + j) * chs, o, tp)
+                                                         : taps_direct(sp + (k0 + j) * HW, tp, W, a.in_scale);
+                            const float wv = blend(t, s);
+                            nz |= (wv != 0.f);              // loss_functions.py:11  (warped == 0).prod(1)
+                            acc += fabsf(tv[j] - wv);       // :12-13
+                        }
+                    }
                 }
             }
         }
-    }
-#pragma unroll
-    for (int vi = 0; vi < NV; ++vi) {
         float m = 1.f;
         if (a.mask) m = fabsf(a.mask[((int64_t)b * NV + vi) * HW + pix]);      // loss_functions_sfm.py:30-31
-        const float r = wave_sum((inside && nz[vi]) ? acc[vi] * m : 0.f);
+        const float r = wave_sum((inside && nz) ? acc * m : 0.f);
         if (threadIdx.x == 0) red[threadIdx.y][vi] = r;
     }
     __syncthreads();
@@ -310,15 +300,15 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
     __shared__ ViewGeo geo[DVF_MAX_VIEWS];
     __shared__ float kinv[9], kmat[9];
     __shared__ float red[TY][DVF_MAX_VIEWS * 12];
-    __shared__ int bbs[TY][DVF_MAX_VIEWS][4];
+    __shared__ int bbs[TY][4];
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int b = blockIdx.z, tid = threadIdx.y * TX + threadIdx.x;
     block_setup(a, b, tid, geo, kinv, kmat);
     const int x = blockIdx.x * TX + threadIdx.x, y = blockIdx.y * TY + threadIdx.y;
     const int W = a.W, H = a.H, C = a.C;
-    const int64_t HW = (int64_t)H * W;
+    const int HW = H * W;
     const bool inside = x < W && y < H;
-    const int64_t pix = (int64_t)min(y, H - 1) * W + min(x, W - 1);
+    const int pix = min(y, H - 1) * W + min(x, W - 1);
     const float scale = a.grad_loss[0] / ((float)a.B * (float)C * (float)H * (float)W);
     const float d = a.depth[(int64_t)b * HW + pix];
     const float u = (float)x, v = (float)y;
@@ -328,79 +318,68 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
     const float cx = c0x * d, cy = c0y * d, cz = c0z * d;
     const float *tg = a.tgt + (int64_t)b * C * HW + pix;
     const bool need_tgt = a.g_tgt != nullptr;
-    bool need_src = false;
-#pragma unroll
-    for (int vi = 0; vi < NV; ++vi) need_src |= a.g_src[vi] != nullptr;
-    Samp sv[NV];
-    TapPos tp[NV];
-    Foot ft[NV];
-    float gixv[NV], giyv[NV], absumv[NV], mv[NV];
-    uint32_t slo[NV], shi[NV];
-    bool nzv[NV];
+    const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float gd = 0.f;
+    float vmv[NV];                                          // validity * explainability * upstream / N per view
+    uint32_t slo[NV], shi[NV];                              // L1 signs per (view, channel)
+    // ---- pass 1, one view at a time: d loss / d ix, iy (without the validity factor), |diff| sum, exact-zero flag and
+    // the L1 signs; then the chain to depth and to the [R|t] gradient partials of that view
 #pragma unroll
     for (int vi = 0; vi < NV; ++vi) {
-        sv[vi] = project<BORDER, ALIGN, PIX>(geo[vi], cx, cy, cz, W, H);
-        tp[vi] = tap_pos(sv[vi], W, H, inside);
-        gixv[vi] = giyv[vi] = absumv[vi] = 0.f;
-        slo[vi] = shi[vi] = 0u;
-        nzv[vi] = false;
-        mv[vi] = a.mask ? a.mask[((int64_t)b * NV + vi) * HW + pix] : 1.f;
-    }
-    footprints<NV>(tp, W, a.vec, bbs, ft);
-    // ---- pass 1: d loss / d ix, iy (without the validity factor), |diff| sums, exact-zero flags and the L1 signs
-    for (int c0 = 0; c0 < C; c0 += PT_CC) {
-        const int nch = min(PT_CC, C - c0);
-        float tv[PT_CC];
-#pragma unroll
-        for (int k = 0; k < PT_CC; ++k) {
-            tv[k] = (k < nch) ? tg[(int64_t)(c0 + k) * HW] : 0.f;
-            if (a.in_scale != 1.f) tv[k] = __fmul_rn(a.in_scale, tv[k]);
-        }
-#pragma unroll
-        for (int vi = 0; vi < NV; ++vi) {
-            const Foot f = ft[vi];
-            if (f.mode == 0) continue;
-            if (f.mode == 1) {
-                __syncthreads();
-                if (!DVF_DBG(a, 8)) stage_tile(tile, a.src[vi], f, b, C, c0, nch, H, W, a.in_scale, a.vec, tid);
-                __syncthreads();
-            }
-            if (!tp[vi].any) continue;
-            const TileOff o = tile_off(tp[vi], f);
+        const Samp s = project<BORDER, ALIGN, PIX>(geo[vi], cx, cy, cz, W, H);
+        const TapPos tp = tap_pos(s, W, H, inside);
+        const Foot f = footprint(tp, a.vec, bbs, DVF_DBG(a, 16));
+        const float m = a.mask ? a.mask[((int64_t)b * NV + vi) * HW + pix] : 1.f;
+        float gix = 0.f, giy = 0.f, absum = 0.f;
+        uint32_t lo = 0u, hi = 0u;
+        bool nzf = false;
+        if (f.mode != 0) {
+            const TileOff o = tile_off(tp, f);
             const int chs = f.rows * f.RS;
-            const float *sp = a.src[vi] + ((int64_t)b * C + c0) * HW;
+            for (int c0 = 0; c0 < C; c0 += PT_CC) {
+                const int nch = min(PT_CC, C - c0);
+                if (f.mode == 1) {
+                    __syncthreads();
+                    if (!DVF_DBG(a, 8)) stage_tile(tile, a.src[vi], f, b, C, c0, nch, H, W, a.in_scale, a.vec, tid);
+                    __syncthreads();
+                }
+                if (!tp.any) continue;
+                const float *sp = a.src[vi] + ((int64_t)b * C + c0) * HW;
+#pragma unroll 1
+                for (int k0 = 0; k0 < nch; k0 += 4) {
+                    float tv[4];
 #pragma unroll
-            for (int k = 0; k < PT_CC; ++k) {
-                if (k < nch) {
-                    const Taps t = (f.mode == 1) ? taps_lds(tile + k * chs, o, tp[vi]) : taps_direct(sp + (int64_t)k * HW, tp[vi], W, a.in_scale);
-                    const float wv = blend(t, sv[vi]);
-                    nzv[vi] |= (wv != 0.f);
-                    const float df = tv[k] - wv;
-                    const float sg = sgn(df * mv[vi]);      // sign of the masked difference
-                    absumv[vi] += fabsf(df);
-                    float dox, doy;
-                    blend_grad(t, sv[vi], dox, doy);
-                    gixv[vi] -= sg * dox;                   // d|.|/d warped = -sign
-                    giyv[vi] -= sg * doy;
-                    sign_put(slo[vi], shi[vi], c0 + k, sg);
+                    for (int j = 0; j < 4; ++j) {
+                        tv[j] = (k0 + j < nch) ? tg[(c0 + k0 + j) * HW] : 0.f;
+                        if (a.in_scale != 1.f) tv[j] = __fmul_rn(a.in_scale, tv[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (k0 + j < nch) {
+                            const Taps t = (f.mode == 1) ? taps_lds(tile + (k0 + j) * chs, o, tp)
+                                                         : taps_direct(sp + (k0 + j) * HW, tp, W, a.in_scale);
+                            const float wv = blend(t, s);
+                            nzf |= (wv != 0.f);
+                            const float df = tv[j] - wv;
+                            const float sg = sgn(df * m);   // sign of the masked difference
+                            absum += fabsf(df);
+                            float dox, doy;
+                            blend_grad(t, s, dox, doy);
+                            gix -= sg * dox;                // d|.|/d warped = -sign
+                            giy -= sg * doy;
+                            sign_put(lo, hi, c0 + k0 + j, sg);
+                        }
+                    }
                 }
             }
         }
-    }
-    // ---- per view: explainability-mask gradient, chain to depth and to the [R|t] partials
-    float gd = 0.f;
-    float vmv[NV];
-    float pacc[NV][12];
-#pragma unroll
-    for (int vi = 0; vi < NV; ++vi) {
-        const Samp &s = sv[vi];
-        const float m = mv[vi];
-        const bool nz = inside && nzv[vi];
-        const float vm = nz ? m * scale : 0.f;              // validity * explainability * upstream / N
+        slo[vi] = lo; shi[vi] = hi;
+        const bool nz = inside && nzf;
+        const float vm = nz ? m * scale : 0.f;
         vmv[vi] = vm;
-        if (a.g_mask && inside) a.g_mask[((int64_t)b * NV + vi) * HW + pix] = nz ? absumv[vi] * sgn(m) * scale : 0.f;
+        if (a.g_mask && inside) a.g_mask[((int64_t)b * NV + vi) * HW + pix] = nz ? absum * sgn(m) * scale : 0.f;
         // chain to the projected point                       cam2pixel, inverse_warp.py:61-66
-        const float gxq = gixv[vi] * vm * s.dix, gyq = giyv[vi] * vm * s.diy;
+        const float gxq = gix * vm * s.dix, gyq = giy * vm * s.diy;
         const float gpx = gxq / s.Z, gpy = gyq / s.Z;
         const float gpz = s.zpass ? -(gxq * s.xq + gyq * s.yq) / s.Z : 0.f;
         const ViewGeo &g = geo[vi];
@@ -409,20 +388,18 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
         const float gcy = g.A[1] * gpx + g.A[4] * gpy + g.A[7] * gpz;
         const float gcz = g.A[2] * gpx + g.A[5] * gpy + g.A[8] * gpz;
         gd += nz ? gcx * c0x + gcy * c0y + gcz * c0z : 0.f;
-        // y = R cam + t ; g_y = K^T g_p ; g_t and g_R = g_y (x) cam
-        const float gyx = nz ? kmat[0] * gpx + kmat[3] * gpy + kmat[6] * gpz : 0.f;
-        const float gyy = nz ? kmat[1] * gpx + kmat[4] * gpy + kmat[7] * gpz : 0.f;
-        const float gyz = nz ? kmat[2] * gpx + kmat[5] * gpy + kmat[8] * gpz : 0.f;
-        pacc[vi][0] = gyx; pacc[vi][1] = gyy; pacc[vi][2] = gyz;
-        pacc[vi][3] = gyx * cx; pacc[vi][4] = gyx * cy; pacc[vi][5] = gyx * cz;
-        pacc[vi][6] = gyy * cx; pacc[vi][7] = gyy * cy; pacc[vi][8] = gyy * cz;
-        pacc[vi][9] = gyz * cx; pacc[vi][10] = gyz * cy; pacc[vi][11] = gyz * cz;
+        if (a.pose_part) {
+            // y = R cam + t ; g_y = K^T g_p ; g_t and g_R = g_y (x) cam ; reduced over the block and stored per block
+            const float gyx = nz ? kmat[0] * gpx + kmat[3] * gpy + kmat[6] * gpz : 0.f;
+            const float gyy = nz ? kmat[1] * gpx + kmat[4] * gpy + kmat[7] * gpz : 0.f;
+            const float gyz = nz ? kmat[2] * gpx + kmat[5] * gpy + kmat[8] * gpz : 0.f;
+            float pacc[1][12] = {{gyx, gyy, gyz, gyx * cx, gyx * cy, gyx * cz, gyy * cx, gyy * cy, gyy * cz, gyz * cx, gyz * cy,
+                                  gyz * cz}};
+            __syncthreads();                                // (red of the previous view fully read)
+            reduce_pose_partials<1>(pacc, 1, a.B, b, nullptr, red, a.pose_part + (blk * NV + vi) * 12);
+        }
     }
     if (a.g_depth && inside) a.g_depth[(int64_t)b * HW + pix] = gd;
-    if (a.pose_part) {
-        const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        reduce_pose_partials<NV>(pacc, NV, a.B, b, nullptr, red, a.pose_part + blk * (NV * 12));
-    }
     // ---- grad target: d loss / d tgt_c = sum over views of sign * validity (x in_scale: the kernel scaled the input)
     if (need_tgt && inside) {
         float *gt = a.g_tgt + (int64_t)b * C * HW + pix;
@@ -430,74 +407,99 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
             float g = 0.f;
 #pragma unroll
             for (int vi = 0; vi < NV; ++vi) g += sign_get(slo[vi], shi[vi], c) * vmv[vi];
-            gt[(int64_t)c * HW] = g * a.in_scale;
+            gt[c * HW] = g * a.in_scale;
         }
     }
+    bool need_src = false;
+#pragma unroll
+    for (int vi = 0; vi < NV; ++vi) need_src |= a.g_src[vi] != nullptr;
     if (!need_src || DVF_DBG(a, 1)) return;                 // (block-uniform)
-    // ---- pass 2: grad source = scatter-add of -g * (bilinear weights), accumulated in the LDS tile per footprint
+    // ---- pass 2: grad source = scatter-add of -g * (bilinear weights), accumulated per footprint in the LDS tile in
+    // fixed point (see the header) and flushed with one row-contiguous global atomic per touched element.  The view's
+    // sampling state is recomputed (same arithmetic, same bits) rather than kept alive across pass 1.
+    int *itile = reinterpret_cast<int *>(tile);
     {
-        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef int i4 __attribute__((ext_vector_type(4)));
         const int tot4 = (min(PT_CC, C) * PT_CAP) >> 2;
         __syncthreads();                                    // (the last staged tile is still being read by slower waves)
-        for (int i = tid; i < tot4; i += 256) reinterpret_cast<f4 *>(tile)[i] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < tot4; i += 256) reinterpret_cast<i4 *>(itile)[i] = i4{0, 0, 0, 0};
     }
-    for (int c0 = 0; c0 < C; c0 += PT_CC) {
-        const int nch = min(PT_CC, C - c0);
 #pragma unroll
-        for (int vi = 0; vi < NV; ++vi) {
-            const Foot f = ft[vi];
-            float *gs = a.g_src[vi];
-            if (!gs || f.mode == 0) continue;               // (block-uniform)
-            const Samp &s = sv[vi];
-            const TapPos &p = tp[vi];
-            const bool act = p.any && vmv[vi] != 0.f;
-            const float gsc = -vmv[vi] * a.in_scale;
-            if (f.mode == 2) {                              // footprint too large for the tile: direct global atomics
-                if (act) {
-                    float *gp = gs + ((int64_t)b * C + c0) * HW + (int64_t)s.y0 * W + s.x0;
-                    for (int k = 0; k < nch; ++k) {
-                        const float g = sign_get(slo[vi], shi[vi], c0 + k) * gsc;
-                        if (g != 0.f) {
-                            if (p.v_nw) atomicAdd(gp, g * s.wnw);
-                            if (p.v_ne) atomicAdd(gp + 1, g * s.wne);
-                            if (p.v_sw) atomicAdd(gp + W, g * s.wsw);
-                            if (p.v_se) atomicAdd(gp + W + 1, g * s.wse);
-                        }
-                        gp += HW;
-                    }
-                }
-                continue;
-            }
-            const int chs = f.rows * f.RS;
-            __syncthreads();                                // tile is all zero here (initial clear / previous flush)
+    for (int vi = 0; vi < NV; ++vi) {
+        float *gs = a.g_src[vi];
+        if (!gs) continue;                                  // (block-uniform)
+        const Samp s = project<BORDER, ALIGN, PIX>(geo[vi], cx, cy, cz, W, H);
+        const TapPos p = tap_pos(s, W, H, inside);
+        const Foot f = footprint(p, a.vec, bbs, DVF_DBG(a, 16));
+        // fixed-point scale from the block's largest |upstream value| (wave max -> LDS -> block max)
+        float gmax = p.any ? fabsf(vmv[vi] * a.in_scale) : 0.f;
+        if (!(gmax == gmax)) gmax = __builtin_inff();       // NaN upstream: handled like inf (direct path)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+        __syncthreads();
+        if (threadIdx.x == 0) bbs[threadIdx.y][0] = __builtin_bit_cast(int, gmax);
+        __syncthreads();
+        gmax = fmaxf(fmaxf(__builtin_bit_cast(float, bbs[0][0]), __builtin_bit_cast(float, bbs[1][0])),
+                     fmaxf(__builtin_bit_cast(float, bbs[2][0]), __builtin_bit_cast(float, bbs[3][0])));
+        gmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gmax)));
+        if (f.mode == 0 || gmax == 0.f) continue;           // nothing to add (block-uniform)
+        // S = 2^(22 - e) with 2^(e-1) <= gmax < 2^e (frexp exponent): every |contribution| * S <= 2^22
+        int e = 0;
+        (void)frexpf(gmax, &e);
+        const bool fx_ok = gmax < 3.0e38f && e > -100 && e < 100;
+        const float fx_scale = ldexpf(1.f, 22 - e), fx_inv = ldexpf(1.f, e - 22);
+        const bool act = p.any && vmv[vi] != 0.f;
+        const float gsc = -vmv[vi] * a.in_scale;
+        if (f.mode == 2 || !fx_ok) {                        // footprint too large for the tile (or inf/NaN upstream)
             if (act) {
-                // true (unclamped) tap positions: a valid tap lies inside the footprint by construction
-                const int o = (s.y0 - f.ylo) * f.RS + (s.x0 - f.xlo);
+                float *gp = gs + (int64_t)b * C * HW + s.y0 * W + s.x0;
+                for (int c = 0; c < C; ++c) {
+                    const float g = sign_get(slo[vi], shi[vi], c) * gsc;
+                    if (g != 0.f) {
+                        if (p.v_nw) atomicAdd(gp, g * s.wnw);
+                        if (p.v_ne) atomicAdd(gp + 1, g * s.wne);
+                        if (p.v_sw) atomicAdd(gp + W, g * s.wsw);
+                        if (p.v_se) atomicAdd(gp + W + 1, g * s.wse);
+                    }
+                    gp += HW;
+                }
+            }
+            continue;
+        }
+        const int chs = f.rows * f.RS;
+        // true (unclamped) tap positions: a valid tap lies inside the footprint by construction
+        const int o = (s.y0 - f.ylo) * f.RS + (s.x0 - f.xlo);
+        const float gq = gsc * fx_scale;                    // exact: power-of-two scale
+        const int inw = p.v_nw ? __float2int_rn(gq * s.wnw) : 0, ine = p.v_ne ? __float2int_rn(gq * s.wne) : 0;
+        const int isw = p.v_sw ? __float2int_rn(gq * s.wsw) : 0, ise = p.v_se ? __float2int_rn(gq * s.wse) : 0;
+        for (int c0 = 0; c0 < C; c0 += PT_CC) {
+            const int nch = min(PT_CC, C - c0);
+            __syncthreads();                                // tile is all zero here (initial clear / previous flush)
+            if (act && !DVF_DBG(a, 4)) {
                 for (int k = 0; k < nch; ++k) {
-                    const float g = sign_get(slo[vi], shi[vi], c0 + k) * gsc;
-                    float *tq = tile + k * chs + o;
-                    if (g != 0.f && !DVF_DBG(a, 4)) {
-                        if (p.v_nw) atomicAdd(tq, g * s.wnw);
-                        if (p.v_ne) atomicAdd(tq + 1, g * s.wne);
-                        if (p.v_sw) atomicAdd(tq + f.RS, g * s.wsw);
-                        if (p.v_se) atomicAdd(tq + f.RS + 1, g * s.wse);
+                    const float sg = sign_get(slo[vi], shi[vi], c0 + k);
+                    int *tq = itile + k * chs + o;
+                    if (sg != 0.f) {
+                        const bool neg = sg < 0.f;          // (-x rounds to -(rint x): the sign can be applied after)
+                        if (p.v_nw) atomicAdd(tq, neg ? -inw : inw);
+                        if (p.v_ne) atomicAdd(tq + 1, neg ? -ine : ine);
+                        if (p.v_sw) atomicAdd(tq + f.RS, neg ? -isw : isw);
+                        if (p.v_se) atomicAdd(tq + f.RS + 1, neg ? -ise : ise);
                     }
                 }
             }
             __syncthreads();
             // flush: one row-contiguous global atomic per touched footprint element, and re-zero the tile
-            {
-                const int total = nch * chs;
-                const float inv_rs = 1.0f / (float)f.RS, inv_rows = 1.0f / (float)f.rows;
-                float *gbase = gs + ((int64_t)b * C + c0) * HW + (int64_t)f.ylo * W + f.xlo;
-                for (int idx = tid; idx < total; idx += 256) {
-                    const float val = tile[idx];
-                    if (val != 0.f) {
-                        const int r = div_small(idx, inv_rs), xx = idx - r * f.RS;
-                        const int ch = div_small(r, inv_rows), yy = r - ch * f.rows;
-                        if (!DVF_DBG(a, 2)) atomicAdd(gbase + ((int64_t)ch * H + yy) * W + xx, val);
-                        tile[idx] = 0.f;
-                    }
+            const int total = nch * chs;
+            const float inv_rs = 1.0f / (float)f.RS, inv_rows = 1.0f / (float)f.rows;
+            float *gbase = gs + ((int64_t)b * C + c0) * HW + f.ylo * W + f.xlo;
+            for (int idx = tid; idx < total; idx += 256) {
+                const int val = itile[idx];
+                if (val != 0) {
+                    const int r = div_small(idx, inv_rs), xx = idx - r * f.RS;
+                    const int ch = div_small(r, inv_rows), yy = r - ch * f.rows;
+                    if (!DVF_DBG(a, 2)) atomicAdd(gbase + (ch * H + yy) * W + xx, (float)val * fx_inv);
+                    itile[idx] = 0;
                 }
             }
         }

@@ -32,12 +32,15 @@ _WS = {}      # (device, stream) -> split-K scratch shared by the convolutions o
 
 def _workspace(nfloats, device):
     """Scratch for split-K partial tiles: one buffer per compute stream (kernels of one stream are ordered, so they can
-    share it); it only grows (in the eager warm-up steps, never inside a graph capture)."""
+    share it); it only grows.  During a HIP-graph capture the current stream is the capture's own, so there is no
+    cached buffer for it: the scratch then comes from the capture's private memory pool (one allocation per call, at
+    capture time only) -- the captured step must run the same split-K reduction as the eager one, not the float-atomic
+    fallback of a missing workspace."""
     key = (device, L.stream().value)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
         if torch.cuda.is_current_stream_capturing():
-            return None
+            return torch.empty(max(int(nfloats), 1), device=device, dtype=torch.float32)
         _WS[key] = buf = torch.empty(max(int(nfloats), 1 << 20), device=device, dtype=torch.float32)
     return buf
 
@@ -51,7 +54,7 @@ def repack_all():
     """Refresh every packed weight copy with one launch per tile-size group (called by FlatAdam.step() right after the
     update, so the convolutions of the next step find their copies current).  The job tables are built once per set of
     layers."""
-    if not L.USE_PIPE or not _PACK_REGISTRY:
+    if not _PACK_REGISTRY:
         return
     lib = L.lib()
     live = [(r, r[0]()) for r in _PACK_REGISTRY]
@@ -113,26 +116,25 @@ def repack_all():
 def _packed_weights(weight, holder, desc, segc, kind):
     """Packed copy of `weight` for the pipelined kernels (kind 0: forward, 1: dgrad), cached on `holder` (the
     parameter) per layer geometry and refreshed when the weights changed.  None when the plan is unsupported."""
-    if not L.USE_PIPE:
-        return None, None
     lib = L.lib()
     cache = holder.__dict__.setdefault("_dvf_pack", {})
     key = (kind, desc.N, desc.H_in, desc.W_in, desc.H_out, desc.W_out, desc.stride, desc.pad, desc.transposed, tuple(segc))
     ent = cache.get(key)
     if ent is None:
         nf = lib.dvf_conv2d_packed_floats(ctypes.byref(desc), L.int_array(segc), len(segc), kind)
+        # split-K scratch of this op (packed and unpacked kernels alike): partial tiles are reduced in a fixed order
+        wsf = max(int(lib.dvf_conv2d_ws_floats(ctypes.byref(desc), L.int_array(segc), len(segc), kind)), 0)
         if nf == L.ERR_UNSUPPORTED:
-            cache[key] = ent = [None, None, 0]
+            cache[key] = ent = [None, None, wsf]
         else:
             if nf < 0:
                 L.check(int(nf), "dvf_conv2d_packed_floats")
             # zero-filled once: padding slots of the packed image are never written again
-            wsf = lib.dvf_conv2d_ws_floats(ctypes.byref(desc), L.int_array(segc), len(segc), kind)
-            cache[key] = ent = [torch.zeros(int(nf), device=weight.device, dtype=torch.float32), None, max(int(wsf), 0)]
+            cache[key] = ent = [torch.zeros(int(nf), device=weight.device, dtype=torch.float32), None, wsf]
             _PACK_REGISTRY.append([weakref.ref(holder), desc, list(segc), kind, ent])
     buf = ent[0]
     if buf is None:
-        return None, None
+        return None, (_workspace(ent[2], weight.device) if ent[2] else None)
     stamp = (weight.data_ptr(), weight._version, L.PACK_EPOCH)
     if ent[1] != stamp:
         with L.timed("conv_pack", 0.0, 8.0 * weight.numel()):
@@ -188,9 +190,10 @@ class ConvFn(torch.autograd.Function):
                 if rc != L.ERR_UNSUPPORTED:             # (unsupported at run time: an operand is not 16-byte aligned)
                     L.check(rc, "dvf_conv2d_fwd_packed")
             if rc == L.ERR_UNSUPPORTED:
-                L.check(L.lib().dvf_conv2d_fwd(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc),
-                                               len(segc), L.dev(weight, "weight"), L.dev(bias, "bias"), L.dev(out),
-                                               L.stream()), "dvf_conv2d_fwd")
+                L.check(L.lib().dvf_conv2d_fwd_ws(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc),
+                                                  len(segc), L.dev(weight, "weight"), L.dev(bias, "bias"), L.dev(out),
+                                                  L.dev(ws), ws.numel() if ws is not None else 0, L.stream()),
+                        "dvf_conv2d_fwd_ws")
         L.note_plans("fwd")
         ctx.save_for_backward(weight, out, *inputs)
         ctx.desc, ctx.segc, ctx.has_bias = desc, segc, bias is not None
@@ -231,8 +234,9 @@ class ConvFn(torch.autograd.Function):
                     if rc != L.ERR_UNSUPPORTED:
                         L.check(rc, "dvf_conv2d_dgrad_packed")
                 if rc == L.ERR_UNSUPPORTED:
-                    L.check(lib.dvf_conv2d_dgrad(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins),
-                                                 L.int_array(segc), len(segc), L.stream()), "dvf_conv2d_dgrad")
+                    L.check(lib.dvf_conv2d_dgrad_ws(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins),
+                                                    L.int_array(segc), len(segc), L.dev(ws),
+                                                    ws.numel() if ws is not None else 0, L.stream()), "dvf_conv2d_dgrad_ws")
             L.note_plans("dgrad")
         dw = None
         if need_w:

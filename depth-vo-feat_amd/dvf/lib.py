@@ -60,6 +60,8 @@ SIGNATURES = {
     "dvf_smooth_loss_bwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_f, c_fp]),
     "dvf_conv2d_fwd": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_fp, c_fp]),
     "dvf_conv2d_dgrad": (c_i, [c_desc, c_fp, c_fp, c_pp, c_ip, c_i, c_fp]),
+    "dvf_conv2d_fwd_ws": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_fp, c_fp, c_i64, c_fp]),
+    "dvf_conv2d_dgrad_ws": (c_i, [c_desc, c_fp, c_fp, c_pp, c_ip, c_i, c_fp, c_i64, c_fp]),
     "dvf_conv2d_wgrad": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_i, c_fp]),
     "dvf_conv2d_packed_floats": (c_i64, [c_desc, c_ip, c_i, c_i]),
     "dvf_conv2d_pack": (c_i, [c_desc, c_ip, c_i, c_i, c_fp, c_fp, c_fp]),
@@ -227,7 +229,6 @@ def join_aux_streams():
 
 
 PACK_EPOCH = 0  # bumped by FlatAdam.step(): packed copies of the convolution weights are stale after it
-USE_PIPE = os.environ.get("DVF_CONV_PIPE", "1") != "0"   # LDS-DMA pipelined conv kernels over pre-packed weights
 
 
 def timed(kind, flops=0.0, nbytes=0.0, tag=""):

@@ -176,6 +176,13 @@ int dvf_conv2d_fwd_packed(const dvf_conv_desc *d, const float *const *in_segs, c
 int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const float *packed, const float *w,
                             float *const *din_segs, const int *seg_channels, int nseg, float *ws, int64_t ws_floats,
                             void *stream);
+/* The unpacked entries with a split-K workspace (>= dvf_conv2d_ws_floats(...) floats; NULL = the float-atomic fallback of
+ * dvf_conv2d_fwd / dvf_conv2d_dgrad): small grids split the reduction over blocks, and with the workspace the partial
+ * tiles are summed in a fixed order -- activations are then bit-reproducible from run to run. */
+int dvf_conv2d_fwd_ws(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                      const float *w, const float *bias, float *out, float *ws, int64_t ws_floats, void *stream);
+int dvf_conv2d_dgrad_ws(const dvf_conv_desc *d, const float *dpre, const float *w, float *const *din_segs,
+                        const int *seg_channels, int nseg, float *ws, int64_t ws_floats, void *stream);
 /* Optional split-K workspace of the packed entries: with ws (>= dvf_conv2d_ws_floats(...) floats, contents
  * irrelevant) small grids split the reduction over blocks that store plain partial tiles which one pass reduces
  * (+bias, activation); with ws == NULL they accumulate with float atomics into a zeroed output instead. */

@@ -83,10 +83,10 @@ def _check_params(g, name, module, sd0, lr, n_steps=2):
         if f"p_{name}_val_{k}" in g:
             # small tensors (<= 4096 elements; one element is up to 2% of a bias' norm): element by element against
             # the reference's values at 1e-5 absolute (0.5% of one Adam step) -- except that an element whose gradient
-            # is at rounding-noise level may step the other way (2*lr per step): at most 1 + 2% of the elements
+            # is at rounding-noise level may step the other way (2*lr per step): at most 2 + 2% of the elements
             dev = (sd[k].double().cpu() - torch.from_numpy(g[f"p_{name}_val_{k}"]).double()).abs()
             assert float(dev.max()) <= 2 * lr * n_steps * 1.01, (k, float(dev.max()))
-            assert int((dev > 1e-5).sum()) <= 1 + 0.02 * dev.numel(), (k, int((dev > 1e-5).sum()), dev.numel())
+            assert int((dev > 1e-5).sum()) <= 2 + 0.02 * dev.numel(), (k, int((dev > 1e-5).sum()), dev.numel())
             continue
         assert abs(float(sd[k].norm()) - n) / max(n, 1e-12) < TOL, k
         upd = sd[k] - sd0[k].double()
