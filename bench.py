@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
-"""Headline benchmark: KITTI 256x832 stereo-sequence training samples/sec (forward + backward + Adam) of the
-DispNetS + PoseExpNet joint step (BASELINE.json configs[1], SURVEY.md section 8d cfg 2), synthetic data.
+"""Headline benchmark: KITTI 256x832 stereo-sequence training samples/sec (forward + backward + Adam) on synthetic data.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {2,3,4,5}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
-One process per GPU (RCCL = torch.distributed backend "nccl"); weak scaling: every rank runs batch 4, gradients
-are sum-all-reduced over flat arena buckets during backward and averaged inside the fused Adam.  Rank 0 prints
-ONE JSON line.  `value` counts samples of all ranks over the slowest rank's time.  Besides the contract keys the
-line carries `roofline` (dominant kernel = the fp32-MFMA gather convolution, measured live with HIP events),
-`roofline_warp` (fused warp+photometric kernels vs HBM) and `cpu_baseline` (the CPU oracle of the same step,
-timed on this host's cores on a bounded sample)."""
+Default workload = BASELINE.json configs[1] (SURVEY.md section 8d cfg 2): DispNetS + PoseExpNet joint step, spatial +
+temporal photometric loss + 10*smooth, 256x832, batch 4 per GPU.  --config selects the other single-GPU-sized cases:
+  3  + FeatExtractor on the three frames and 0.1 * feature reconstruction (C=32 warps, all gradients), batch 8
+  4  train.py's 4-scale body (masks, smooth, stereo-pose MSE) + the feature term, batch 4 per GPU (32 on 8 GPUs)
+  5  384x1280, five-frame window (nb_ref_imgs = 4), 4 scales, batch 8 per GPU (64 on 8 GPUs)
+
+One process per GPU (RCCL = torch.distributed backend "nccl"); weak scaling: every rank runs the per-GPU batch, gradients
+are sum-all-reduced over flat arena buckets during backward and averaged inside the fused Adam.  Started WITHOUT a
+launcher, `--gpus N` (N > 1) spawns the N rank processes itself before any GPU call.  Rank 0 prints ONE JSON line:
+`value` counts samples of all ranks over the slowest rank's time; `roofline*` objects come from HIP-event brackets around
+every kernel call of one serialised step measured live; `cpu_baseline` is the CPU oracle timed on this host."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,39 +28,82 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "depth-vo-feat_amd"))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 
+CONFIGS = {
+    2: dict(batch=4, height=256, width=832, body="unsupervise", feat=False, nb_ref=2,
+            name="cfg2: DispNetS+PoseExpNet joint step, spatial+temporal photometric (V=2) + 10*smooth, Adam"),
+    3: dict(batch=8, height=256, width=832, body="unsupervise", feat=True, nb_ref=2,
+            name="cfg3: cfg2 + FeatExtractor on 3 frames + 0.1*feature reconstruction (C=32, V=2, all gradients), Adam"),
+    4: dict(batch=4, height=256, width=832, body="train_sfm", feat=True, nb_ref=2,
+            name="cfg4: DispNetS+PoseExpNet_sfm+FeatExtractor, 4-scale photometric with masks + 0.1*smooth + stereo-pose "
+                 "MSE + 0.1*feature reconstruction, Adam"),
+    5: dict(batch=8, height=384, width=1280, body="train_sfm", feat=False, nb_ref=4,
+            name="cfg5: DispNetS+PoseExpNet_sfm(nb_ref_imgs=4), five-frame window, 4-scale photometric with masks (V=4) + "
+                 "0.1*smooth + stereo-pose MSE, Adam"),
+}
 
-def build(args, device, world):
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) ourselves.  This parent
+    has made no GPU call; it relays rank 0's JSON line and exits with the worst return code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
+def build(args, cfg, device, world, rank):
+    import torch
     import DispNetS
-    import PoseExpNet
     from dvf.engine import FlatAdam
-    from dvf.steps import unsupervise_losses
+    from dvf import steps as S
     from dvf.synthetic import synthetic_batch
     torch.manual_seed(args.seed)
+    nets = []
     disp_net = DispNetS.DispNetS()
-    pose_net = PoseExpNet.PoseExpNet(output_exp=True)
-    disp_net.init_weights()
-    pose_net.init_weights()
-    disp_net.to(device).train()
-    pose_net.to(device).train()
-    rank = dist.get_rank() if world > 1 else 0
-    batch = synthetic_batch(args.batch, args.height, args.width, seed=1234, rank=rank, device=device)
-    # unsupervise.py:241  Adam(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)
+    if cfg["body"] == "unsupervise":
+        import PoseExpNet
+        pose_net = PoseExpNet.PoseExpNet(output_exp=True)
+    else:
+        import PoseExpNet_sfm
+        pose_net = PoseExpNet_sfm.PoseExpNet(nb_ref_imgs=cfg["nb_ref"], output_exp=True)
+    feat_net = None
+    if cfg["feat"]:
+        import feat_extractor
+        feat_net = feat_extractor.FeatExtractor()
+    nets = [pose_net, disp_net] + ([feat_net] if feat_net is not None else [])
+    for n in nets:
+        n.init_weights()
+        n.to(device).train()
+    batch = synthetic_batch(args.batch, args.height, args.width, seed=1234, rank=rank, device=device, n_views=cfg["nb_ref"])
     ddp = world > 1 or args.force_ddp
-    opt = FlatAdam(list(pose_net.parameters()) + list(disp_net.parameters()), lr=1e-3, weight_decay=1e-8,
-                   world_size=world, overlap=args.no_graph, always_reduce=ddp)
+    params = [p for n in nets for p in n.parameters()]
+    if cfg["body"] == "unsupervise":      # unsupervise.py:241  Adam(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)
+        opt = FlatAdam(params, lr=1e-3, weight_decay=1e-8, world_size=world, overlap=args.no_graph, always_reduce=ddp)
+    else:                                 # train.py:150-156  Adam(lr=2e-4, betas=(0.9, 0.999), weight_decay=0)
+        opt = FlatAdam(params, lr=2e-4, weight_decay=0.0, world_size=world, overlap=args.no_graph, always_reduce=ddp)
 
     def fwd_bwd():
-        loss, terms = unsupervise_losses(disp_net, pose_net, batch)
+        if cfg["body"] == "unsupervise":
+            loss, terms = S.unsupervise_losses(disp_net, pose_net, batch, feat_extractor=feat_net)
+        else:
+            loss, terms = S.train_sfm_losses(disp_net, pose_net, batch, feat_extractor=feat_net)
         opt.zero_grad()
         loss.backward()
         opt.join_wgrad()                # weight-gradient stream joins the main stream
-        return (terms["total"], terms["img"], terms["smooth"])
+        return (terms["total"],)
 
     def step():
         out = fwd_bwd()
@@ -65,11 +114,11 @@ def build(args, device, world):
 
 
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed PMC summary (profiles/r01_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, read side corrected x2 as calibrated
-    there).  PMC passes cannot run inside the timed process, so the bench line quotes the committed measurement."""
+    """HBM-side bytes per launch of `kernel` from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes over this same command; corrections as calibrated in that file).  PMC passes cannot run inside the
+    timed process, so the bench line QUOTES the committed measurement (see `traffic_source`)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             ks = json.load(f)["kernels"]
         names = {"conv_fwd_dgrad": ["conv_pipe", "conv_gather"]}.get(kernel, [kernel])
         ks = [ks[n] for n in names if n in ks]
@@ -78,6 +127,9 @@ def pmc_traffic(kernel):
         return sum(k["read_bytes_per_step"] + k["write_bytes_per_step"] for k in ks) / sum(k["launches_per_step"] for k in ks)
     except (OSError, KeyError, ValueError):
         return None
+
+
+TRAFFIC_FILE = "r02_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_traffic.json")) else "r01_traffic.json"
 
 
 def measure_kernels(step):
@@ -111,26 +163,54 @@ def host_cores():
     return n
 
 
-def cpu_baseline(args):
-    """The CPU oracle (plain torch CPU restatement of the reference path, pinned to the reference by
-    tests/golden) running the SAME step body at the same resolution, batch 1, a few iterations."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline():
+    """the CPU oracle (plain torch CPU restatement of the reference path, pinned to the reference by
+    tests/golden) on this host's cores -- config 1 EXACTLY (DispNetS depth-only, stereo photometric L1 + 10*smooth,
+    128x416, batch 1, forward + backward + Adam), min of >= 5 iterations after 2 warm-ups, plus the config-2 loss-only
+    micro-benchmark (2 image warps + smooth, 256x832, batch 4, forward + backward).  Bounded to ~10-20 s."""
+    import torch
     from oracle import nets as onets
     from oracle import steps as osteps
     nthreads = host_cores()
     torch.set_num_threads(nthreads)
     dsd = onets.fill_params(onets.dispnet_layers(), seed=1)
-    psd = onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2)
-    batch = osteps.synthetic_batch(1, args.height, args.width, seed=1234)
+    batch = osteps.synthetic_batch(1, 128, 416, seed=1234)
     st = None
-    _, _, st = osteps.step_unsupervise(dsd, psd, batch, st)          # warm-up
-    n, t0 = 0, time.perf_counter()
-    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 20):
-        _, _, st = osteps.step_unsupervise(dsd, psd, batch, st)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "samples/s", "cores": nthreads, "kind": "port",
-            "sample": f"{n} iterations of the same step (DispNetS+PoseExpNet, photometric V=2 + 10*smooth, Adam) at "
-                      f"{args.height}x{args.width}, batch 1, torch CPU fp32, {nthreads} threads"}
+    for _ in range(2):
+        _, _, st = osteps.step_depth_only(dsd, batch, st)
+    times, t_all = [], time.perf_counter()
+    while len(times) < 5 or (time.perf_counter() - t_all < 8.0 and len(times) < 30):
+        t0 = time.perf_counter()
+        _, _, st = osteps.step_depth_only(dsd, batch, st)
+        times.append(time.perf_counter() - t0)
+    # loss-only micro-benchmark
+    b4 = osteps.synthetic_batch(4, 256, 832, seed=1234)
+    g = torch.Generator().manual_seed(7)
+    depth = torch.rand(4, 256, 832, generator=g) * 20 + 2
+    T = torch.randn(4, 6, generator=g) * 0.01
+    osteps.loss_only(b4, depth, T)
+    lt = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        osteps.loss_only(b4, depth, T)
+        lt.append(time.perf_counter() - t0)
+    return {"value": 1.0 / min(times), "unit": "samples/s", "cores": nthreads, "kind": "port", "cpu": cpu_model(),
+            "sample": f"config 1 exactly: DispNetS depth-only, stereo photometric L1 + 10*smooth, 128x416, batch 1, "
+                      f"fwd+bwd+Adam, torch CPU fp32, {nthreads} threads; min of {len(times)} iterations after 2 warm-ups "
+                      f"({1e3 * min(times):.0f} ms)",
+            "loss_only": {"value": 4.0 / min(lt), "unit": "samples/s",
+                          "sample": f"config-2 loss only: 2 image warps (C=3) + smooth, 256x832, batch 4, fwd+bwd, min of 5 "
+                                    f"({1e3 * min(lt):.0f} ms)"}}
 
 
 def main():
@@ -138,16 +218,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (cfg 2: 4)")
-    ap.add_argument("--height", type=int, default=256)
-    ap.add_argument("--width", type=int, default=832)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="workload (SURVEY.md section 8d); default 2 = the headline")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the whole step from one HIP graph (10.35 ms/step at cfg 2 on the round-1 box)")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="eager launches on three streams (9.62 ms/step there; the host enqueues a step in 7.2 ms)")
+    ap.add_argument("--graph", action="store_true", help="replay the whole step from one HIP graph")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches on three streams")
     # default (neither flag, one GPU): both are built, each is timed for a few untimed steps, the faster one is used --
-    # which of the two wins depends on how fast the host enqueues ~360 launches per step
+    # which of the two wins depends on how fast the host enqueues the ~360 launches of a step
     ap.add_argument("--force-ddp", action="store_true", help="run the multi-GPU exchange path even with one rank")
     ap.add_argument("--graph-ddp", action="store_true",
                     help="multi-GPU: replay forward+backward from a HIP graph and all-reduce afterwards (no overlap); "
@@ -157,10 +236,21 @@ def main():
     ap.add_argument("--serialize", action="store_true",
                     help="no side streams (weight gradients, pose network) -- for per-kernel profiles; not the headline")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    for k in ("batch", "height", "width"):
+        if getattr(args, k) is None:
+            setattr(args, k, cfg[k])
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args.gpus)            # (does not return)
+
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} or without a launcher")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -169,8 +259,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     def log(msg):
         if rank == 0:
@@ -179,13 +267,13 @@ def main():
     if args.serialize:
         from dvf import lib as _L
         _L.SERIALIZE = True
-    log("building models")
+    log("building models (config %d)" % args.config)
     auto = not args.graph and not args.no_graph and world == 1 and not args.force_ddp and not args.serialize
     if world > 1 or args.force_ddp:
         args.no_graph = not args.graph_ddp
     elif not args.graph:
         args.no_graph = True
-    step, fwd_bwd, opt, ddp = build(args, device, world)
+    step, fwd_bwd, opt, ddp = build(args, cfg, device, world, rank)
     use_graph = not args.no_graph
     from dvf.engine import GraphedStep
     if auto:
@@ -246,6 +334,17 @@ def main():
         dt = float(tt.item())
     loss = float(out[0])
 
+    # the data-parallel exchange on its own: the gradient arena all-reduced in the step's buckets, nothing overlapping it
+    allreduce_ms = None
+    if ddp:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            for b in opt.buckets:
+                dist.all_reduce(opt.flat_g[b["start"]:b["end"]], op=dist.ReduceOp.SUM)
+        fence()
+        allreduce_ms = 1e3 * (time.perf_counter() - t1) / 5
+
     result = None
     if rank == 0:
         samples = args.batch * world * args.steps
@@ -253,54 +352,66 @@ def main():
             "metric": "KITTI 256x832 stereo-seq samples/sec fwd+bwd", "value": samples / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg2: DispNetS+PoseExpNet joint step, spatial+temporal photometric (V=2) + "
-                                   "10*smooth, Adam; %dx%d, batch %d per GPU" % (args.height, args.width, args.batch),
+            "config": {"workload": "%s; %dx%d, batch %d per GPU" % (cfg["name"], args.height, args.width, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "launch": ("hipgraph" if use_graph else "eager") + ("+rccl-allreduce" if ddp else "")},
             "final_loss": loss,
         }
+        if ddp:
+            result["rccl_world_size"] = dist.get_world_size()
+            result["allreduce_ms_per_step"] = allreduce_ms
+            result["allreduce_bytes_per_step"] = 4 * int(opt.total)
+            result["allreduce_note"] = ("gradient arena in %d buckets, measured alone after the timed region; inside a step it "
+                                        "runs on the communication stream under backward" % len(opt.buckets))
     log("timed region done: %.2f ms/step" % (1e3 * dt / args.steps))
     ks = None
     if not args.no_kernel_timing:
-        # every rank runs the extra eager step (it contains the gradient all-reduce); rank 0 records
+        # every rank runs the extra eager steps (they contain the gradient all-reduce); rank 0 records
         if rank == 0:
             ks = measure_kernels(step)
         else:
+            step()
             step()
     if rank == 0 and ks is not None:
         g_ms = ks.get("conv_fwd", {}).get("ms", 0) + ks.get("conv_dgrad", {}).get("ms", 0)
         g_fl = ks.get("conv_fwd", {}).get("flops", 0) + ks.get("conv_dgrad", {}).get("flops", 0)
         g_calls = ks.get("conv_fwd", {}).get("calls", 0) + ks.get("conv_dgrad", {}).get("calls", 0)
         ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-        result["roofline"] = {"kernel": "conv_pipe_kernel + conv_gather_kernel (Conv2d/ConvTranspose2d forward + dgrad; "
-                                        "a call = the convolution launch plus its split-K reduce / memset where used)",
+        quoted = args.config == 2 and args.batch == 4
+        result["roofline"] = {"kernel": "conv_pipe_kernel + conv_gather_kernel + head kernels (Conv2d/ConvTranspose2d forward + "
+                                        "dgrad; a call = the convolution launch plus its split-K reduce where used)",
                               "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic("conv_fwd_dgrad"),
-                              "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_traffic.json)", "calls_per_step": g_calls,
-                              "ms_per_step": g_ms}
+                              "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic("conv_fwd_dgrad") if quoted else None,
+                              "traffic_source": ("profiles/%s: HBM-side bytes per launch from separate rocprofv3 --pmc passes of "
+                                                 "this command (committed; not measured in this run)" % TRAFFIC_FILE) if quoted else None,
+                              "calls_per_step": g_calls, "ms_per_step": g_ms}
         w = ks.get("conv_wgrad", {})
         if w.get("ms", 0) > 0:
             a = w["flops"] / (w["ms"] * 1e-3) / 1e12
             result["roofline_wgrad"] = {"kernel": "conv_wgrad_kernel", "bound": "mfma", "achieved": a,
                                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": a / PEAK_FP32_MFMA_TFLOPS,
-                                        "traffic": pmc_traffic("conv_wgrad"), "calls_per_step": w["calls"], "ms_per_step": w["ms"]}
+                                        "traffic": pmc_traffic("conv_wgrad") if quoted else None, "calls_per_step": w["calls"],
+                                        "ms_per_step": w["ms"]}
         p_ms = ks.get("photo_fwd", {}).get("ms", 0) + ks.get("photo_bwd", {}).get("ms", 0)
         p_by = ks.get("photo_fwd", {}).get("bytes", 0) + ks.get("photo_bwd", {}).get("bytes", 0)
         if p_ms > 0:
             a = p_by / (p_ms * 1e-3) / 1e9
-            result["roofline_warp"] = {"kernel": "photo_fwd_kernel + photo_bwd_kernel (fused warp + photometric L1)",
+            result["roofline_warp"] = {"kernel": "photo_fwd_kernel + photo_bwd_kernel (fused warp + photometric L1, all "
+                                                 "scales and the feature term of the step)",
                                        "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                        "frac": a / PEAK_HBM_GBPS,
-                                       "traffic": (pmc_traffic("photo_fwd") or 0) + (pmc_traffic("photo_bwd") or 0) or None,
-                                       "algorithmic_bytes": p_by, "ms_per_step": p_ms}
+                                       "traffic": ((pmc_traffic("photo_fwd") or 0) + (pmc_traffic("photo_bwd") or 0) or None) if quoted else None,
+                                       "algorithmic_bytes": p_by, "ms_per_step": p_ms,
+                                       "calls_per_step": ks.get("photo_fwd", {}).get("calls", 0) + ks.get("photo_bwd", {}).get("calls", 0)}
         result["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(ks.items())}
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.force_ddp and not args.no_cpu_baseline:
         log("cpu baseline")
-        result["cpu_baseline"] = cpu_baseline(args)
+        result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(result))
+        sys.stdout.flush()
     if world > 1 or args.force_ddp:
         dist.barrier()
         dist.destroy_process_group()

@@ -63,8 +63,23 @@ def unsupervise_losses(depth_net, pose_net, batch, feat_extractor=None, img_scal
     return loss, terms
 
 
+def depth_only_losses(depth_net, batch, img_scale=0.004, smooth_weight=10.0, depth_eps=1e-4):
+    """BASELINE.json configs[0] (cfg 1): DispNetS alone with the stereo photometric loss (one view: the left image warped
+    into the right one with the fixed baseline pose) + 10 * smooth -- unsupervise.py:94-102 without the pose network."""
+    R2, L2 = batch["img_R2"], batch["img_L2"]
+    depth = reciprocal(depth_net(R2)[0], depth_eps)                # [B,1,H,W]
+    from dvf.ops import PhotoLossFn
+    photo = PhotoLossFn.apply(R2, depth.squeeze(1), batch["T_R2L"].unsqueeze(0).contiguous(), batch["K"], batch["Kinv"], None,
+                              (0, float(img_scale)), L2)
+    smooth = LF.smooth_loss(depth)
+    loss = photo + smooth_weight * smooth
+    return loss, {"img": photo.detach(), "smooth": smooth.detach(), "total": loss.detach()}
+
+
 def train_sfm_losses(disp_net, pose_exp_net, batch, w1=1.0, w2=0.0, w3=0.1, smooth_factor=2.0,
-                     rotation_mode="euler", padding_mode="zeros"):
+                     rotation_mode="euler", padding_mode="zeros", feat_extractor=None, feat_weight=0.1):
+    """train.py:179-203.  feat_extractor: BASELINE.json configs[3] (cfg 4) adds the feature-reconstruction term of
+    unsupervise.py:104-111 (single scale, finest depth, the network's two poses) to the 4-scale body."""
     tgt = batch["img_R2"]
     refs = [batch["img_R1"], batch["img_L2"]] + list(batch.get("extra_refs", []))[: pose_exp_net.nb_ref_imgs - 2]
     (masks, pose), disparities = _side_by_side(lambda: pose_exp_net(tgt, refs), lambda: disp_net(tgt))   # train.py:187,189
@@ -79,6 +94,14 @@ def train_sfm_losses(disp_net, pose_exp_net, batch, w1=1.0, w2=0.0, w3=0.1, smoo
         l2 = LS.explainability_loss(masks)                         # :195-196
         loss = loss + w2 * l2
         terms["exp"] = l2.detach()
+    if feat_extractor is not None:
+        b = tgt.size(0)
+        feat = feat_extractor(torch.cat((refs[1], tgt, refs[0]), dim=0))    # (L2, R2, R1) as unsupervise.py:104-105
+        f_L2, f_R2, f_R1 = feat[:b], feat[b:2 * b], feat[2 * b:]
+        lf = LF.photometric_reconstruction_loss(f_R2, f_R1, f_L2, depth[0].squeeze(1), pose[:, 0], pose[:, 1], batch["K"],
+                                                batch["Kinv"], rotation_mode, padding_mode)
+        loss = loss + feat_weight * lf
+        terms["feat"] = lf.detach()
     terms["total"] = loss.detach()
     return loss, terms
 

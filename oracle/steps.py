@@ -115,11 +115,54 @@ def step_unsupervise(disp_sd, pose_sd, batch, adam_state=None, lr=1e-3, weight_d
     return out, grads, adam_state
 
 
+def step_depth_only(disp_sd, batch, adam_state=None, lr=1e-3, weight_decay=1e-8, img_scale=0.004, smooth_weight=10.0,
+                    do_update=True):
+    """BASELINE.json configs[0] (cfg 1): DispNetS alone, stereo photometric loss (the left image warped into the right
+    one with the fixed baseline pose, one view) + 10 * smooth -- the unsupervise.py body (:94-102) without the pose
+    network and the temporal view; the loss is loss_functions_sfm's single-scale, single-view form."""
+    dsd = _leaf(disp_sd)
+    R2, L2 = batch["img_R2"], batch["img_L2"]
+    disp = nets.dispnet_forward(dsd, R2)[0]
+    depth = 1 / (disp + 1e-4)
+    photo = losses.photometric_reconstruction_loss_sfm(img_scale * R2, [img_scale * L2], batch["K"], batch["Kinv"], [depth],
+                                                       [None], batch["T_R2L"].unsqueeze(1))
+    smooth = losses.smooth_loss(depth)
+    total = photo + smooth_weight * smooth
+    out = {"img": photo.detach(), "smooth": smooth.detach(), "total": total.detach()}
+    total.backward()
+    grads = {"disp": {k: v.grad for k, v in dsd.items() if v.grad is not None}}
+    if do_update:
+        if adam_state is None:
+            adam_state = {}
+        st = adam_state.setdefault("disp", adam_init(disp_sd))
+        with torch.no_grad():
+            upd = {k: v for k, v in disp_sd.items() if k in grads["disp"]}
+            sub = {"step": st["step"], "m": {k: st["m"][k] for k in upd}, "v": {k: st["v"][k] for k in upd}}
+            adam_step(upd, grads["disp"], sub, lr, weight_decay=weight_decay)
+            st["step"] = sub["step"]
+    return out, grads, adam_state
+
+
+def loss_only(batch, depth, T_2to1, img_scale=0.004, smooth_weight=10.0):
+    """BASELINE.md section 3's loss-only micro-benchmark body: 2 image warps (C=3) + smooth, forward + backward to
+    depth and pose."""
+    depth = depth.detach().clone().requires_grad_(True)
+    T = T_2to1.detach().clone().requires_grad_(True)
+    l = losses.photometric_reconstruction_loss(img_scale * batch["img_R2"], img_scale * batch["img_R1"], img_scale * batch["img_L2"],
+                                               depth, T, batch["T_R2L"], batch["K"], batch["Kinv"]) + \
+        smooth_weight * losses.smooth_loss(depth.unsqueeze(1))
+    l.backward()
+    return l.detach(), depth.grad, T.grad
+
+
 def step_train_sfm(disp_sd, pose_sd, batch, adam_state=None, lr=2e-4, w1=1.0, w2=0.0, w3=0.1,
                    smooth_factor=2.0, nb_ref_imgs=2, rotation_mode="euler", padding_mode="zeros",
-                   do_update=True):
-    """One train.py iteration (train.py:179-214)."""
+                   do_update=True, feat_sd=None, feat_weight=0.1):
+    """One train.py iteration (train.py:179-214).  feat_sd: BASELINE.json configs[3] (cfg 4) adds the feature
+    reconstruction term of unsupervise.py:104-111 (FeatExtractor on the three frames, single-scale photometric loss on
+    the 32-channel maps with the finest depth and the network's two poses, weight 0.1) to the 4-scale body."""
     dsd, psd = _leaf(disp_sd), _leaf(pose_sd)
+    fsd = _leaf(feat_sd) if feat_sd is not None else None
     tgt = batch["img_R2"]
     refs = [batch["img_R1"], batch["img_L2"]] + list(batch.get("extra_refs", []))[: nb_ref_imgs - 2]
     disps = nets.dispnet_forward(dsd, tgt)                                    # :187
@@ -131,11 +174,20 @@ def step_train_sfm(disp_sd, pose_sd, batch, adam_state=None, lr=2e-4, w1=1.0, w2
     l3 = losses.smooth_loss(depth, smooth_factor)                             # :200
     l4 = F.mse_loss(pose[:, 1], batch["T_R2L"])                               # :201
     total = w1 * l1 + w2 * l2 + w3 * l3 + l4                                  # :203
-    out = {"photo": l1.detach(), "smooth": l3.detach(), "lr": l4.detach(), "total": total.detach()}
+    out = {"photo": l1.detach(), "smooth": l3.detach(), "lr": l4.detach()}
     if w2 > 0:
         out["exp"] = l2.detach()
+    if fsd is not None:
+        b = tgt.shape[0]
+        feat = nets.featnet_forward(fsd, torch.cat((refs[1], tgt, refs[0]), 0))          # (L2, R2, R1) as unsupervise.py:104
+        f_L2, f_R2, f_R1 = feat[:b], feat[b:2 * b], feat[2 * b:]
+        lf = losses.photometric_reconstruction_loss(f_R2, f_R1, f_L2, depth[0].squeeze(1), pose[:, 0], pose[:, 1],
+                                                    batch["K"], batch["Kinv"], rotation_mode, padding_mode)
+        total = total + feat_weight * lf
+        out["feat"] = lf.detach()
+    out["total"] = total.detach()
     total.backward()
-    groups = [("disp", disp_sd, dsd), ("pose", pose_sd, psd)]
+    groups = [("disp", disp_sd, dsd), ("pose", pose_sd, psd)] + ([("feat", feat_sd, fsd)] if fsd is not None else [])
     grads = {g: {k: v.grad for k, v in leaf.items() if v.grad is not None} for g, _, leaf in groups}
     if do_update:
         if adam_state is None:
