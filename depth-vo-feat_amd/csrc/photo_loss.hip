@@ -27,8 +27,10 @@ namespace {
 
 using namespace dvfw;
 
-constexpr int PT_CC = 16;         // channels per staged chunk
-constexpr int PT_CAP = 600;       // floats per channel of a footprint tile (68 x 5 typical; up to 120 x 5 / 72 x 8): 16 channels = 38.4 KB, four blocks per CU
+constexpr int PT_CC = 16;         // channels per staged chunk (at most; fewer when the footprint is large)
+constexpr int PT_CAP = 600;       // LDS floats per channel at PT_CC channels: a 68 x 5 footprint (typical) needs 340;
+                                  // larger footprints (wild depth: random-init networks) take fewer channels per round
+constexpr int PT_MIN_TILE = 4096; // floats: LDS tile of the few-channel (image) launches
 constexpr int PT_MAXC = 32;       // the backward kernel keeps one L1 sign per (view, channel) in two 32-bit fields
 
 struct PhotoArgs {
@@ -44,6 +46,7 @@ struct PhotoArgs {
     uint32_t quat;
     float in_scale;
     int vec;                       // sources may be staged in 16-byte lanes (W % 4 == 0, 16-byte aligned bases)
+    int tile_floats;               // size of the dynamic LDS tile
     int dbg;                       // ablation switches (-DDVF_TUNING builds only): 1 no pass 2, 2 no flush atomics, 4 no LDS adds, 8 no staging, 16 no LDS tiles at all
 };
 
@@ -84,10 +87,10 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 // Footprint of the block's pixels in one source view (block-uniform).
-struct Foot { int xlo, ylo, RS, rows, mode; };       // mode 0: no valid tap, 1: LDS tile, 2: direct (does not fit)
+struct Foot { int xlo, ylo, RS, rows, mode, cc; };   // mode 0: no valid tap, 1: LDS tile (cc channels per round), 2: direct (does not fit)
 
 // Block reduction of one view's tap positions to its footprint (two barriers).
-__device__ __forceinline__ Foot footprint(const TapPos &p, int vec, int (*bbs)[4], bool force_direct) {
+__device__ __forceinline__ Foot footprint(const TapPos &p, int vec, int (*bbs)[4], int tile_floats, bool force_direct) {
     const int mnx = wave_min_i(p.any ? p.xb : 0x7fffffff), mxx = wave_max_i(p.any ? p.xb + 1 : -1);
     const int mny = wave_min_i(p.any ? p.y0 : 0x7fffffff), mxy = wave_max_i(p.any ? p.y1 : -1);
     __syncthreads();                                        // (bbs of the previous view fully read)
@@ -107,7 +110,9 @@ __device__ __forceinline__ Foot footprint(const TapPos &p, int vec, int (*bbs)[4
     f.ylo = y0;
     f.RS = vec ? ((x1 - f.xlo + 1 + 3) & ~3) : (x1 - f.xlo + 1);
     f.rows = y1 - y0 + 1;
-    f.mode = (x1 < 0) ? 0 : ((f.RS * f.rows <= PT_CAP && f.RS <= 256 && !force_direct) ? 1 : 2);
+    const int fp = f.RS * f.rows;
+    f.cc = (x1 < 0 || fp <= 0) ? 0 : min(PT_CC, tile_floats / fp);
+    f.mode = (x1 < 0) ? 0 : ((f.cc >= 1 && f.RS <= 256 && !force_direct) ? 1 : 2);
     return f;
 }
 
@@ -218,14 +223,15 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(PhotoArgs a) {
     for (int vi = 0; vi < NV; ++vi) {
         const Samp s = project<BORDER, ALIGN, PIX>(geo[vi], cx, cy, cz, W, H);
         const TapPos tp = tap_pos(s, W, H, inside);
-        const Foot f = footprint(tp, a.vec, bbs, DVF_DBG(a, 16));
+        const Foot f = footprint(tp, a.vec, bbs, a.tile_floats, DVF_DBG(a, 16));
         float acc = 0.f;
         bool nz = false;
         if (f.mode != 0) {                                  // (mode 0: no pixel of the block samples inside this source)
             const TileOff o = tile_off(tp, f);
             const int chs = f.rows * f.RS;
-            for (int c0 = 0; c0 < C; c0 += PT_CC) {
-                const int nch = min(PT_CC, C - c0);
+            const int cstep = f.mode == 1 ? f.cc : PT_CC;
+            for (int c0 = 0; c0 < C; c0 += cstep) {
+                const int nch = min(cstep, C - c0);
                 if (f.mode == 1) {
                     __syncthreads();                        // previous tile fully consumed
                     if (!DVF_DBG(a, 8)) stage_tile(tile, a.src[vi], f, b, C, c0, nch, H, W, a.in_scale, a.vec, tid);
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
     for (int vi = 0; vi < NV; ++vi) {
         const Samp s = project<BORDER, ALIGN, PIX>(geo[vi], cx, cy, cz, W, H);
         const TapPos tp = tap_pos(s, W, H, inside);
-        const Foot f = footprint(tp, a.vec, bbs, DVF_DBG(a, 16));
+        const Foot f = footprint(tp, a.vec, bbs, a.tile_floats, DVF_DBG(a, 16));
         const float m = a.mask ? a.mask[((int64_t)b * NV + vi) * HW + pix] : 1.f;
         float gix = 0.f, giy = 0.f, absum = 0.f;
         uint32_t lo = 0u, hi = 0u;
@@ -336,8 +342,9 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
         if (f.mode != 0) {
             const TileOff o = tile_off(tp, f);
             const int chs = f.rows * f.RS;
-            for (int c0 = 0; c0 < C; c0 += PT_CC) {
-                const int nch = min(PT_CC, C - c0);
+            const int cstep = f.mode == 1 ? f.cc : PT_CC;
+            for (int c0 = 0; c0 < C; c0 += cstep) {
+                const int nch = min(cstep, C - c0);
                 if (f.mode == 1) {
                     __syncthreads();
                     if (!DVF_DBG(a, 8)) stage_tile(tile, a.src[vi], f, b, C, c0, nch, H, W, a.in_scale, a.vec, tid);
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
     int *itile = reinterpret_cast<int *>(tile);
     {
         typedef int i4 __attribute__((ext_vector_type(4)));
-        const int tot4 = (min(PT_CC, C) * PT_CAP) >> 2;
+        const int tot4 = a.tile_floats >> 2;
         __syncthreads();                                    // (the last staged tile is still being read by slower waves)
         for (int i = tid; i < tot4; i += 256) reinterpret_cast<i4 *>(itile)[i] = i4{0, 0, 0, 0};
     }
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
         if (!gs) continue;                                  // (block-uniform)
         const Samp s = project<BORDER, ALIGN, PIX>(geo[vi], cx, cy, cz, W, H);
         const TapPos p = tap_pos(s, W, H, inside);
-        const Foot f = footprint(p, a.vec, bbs, DVF_DBG(a, 16));
+        const Foot f = footprint(p, a.vec, bbs, a.tile_floats, DVF_DBG(a, 16));
         // fixed-point scale from the block's largest |upstream value| (wave max -> LDS -> block max)
         float gmax = p.any ? fabsf(vmv[vi] * a.in_scale) : 0.f;
         if (!(gmax == gmax)) gmax = __builtin_inff();       // NaN upstream: handled like inf (direct path)
@@ -472,8 +479,8 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
         const float gq = gsc * fx_scale;                    // exact: power-of-two scale
         const int inw = p.v_nw ? __float2int_rn(gq * s.wnw) : 0, ine = p.v_ne ? __float2int_rn(gq * s.wne) : 0;
         const int isw = p.v_sw ? __float2int_rn(gq * s.wsw) : 0, ise = p.v_se ? __float2int_rn(gq * s.wse) : 0;
-        for (int c0 = 0; c0 < C; c0 += PT_CC) {
-            const int nch = min(PT_CC, C - c0);
+        for (int c0 = 0; c0 < C; c0 += f.cc) {
+            const int nch = min(f.cc, C - c0);
             __syncthreads();                                // tile is all zero here (initial clear / previous flush)
             if (act && !DVF_DBG(a, 4)) {
                 for (int k = 0; k < nch; ++k) {
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(256) void pose_sum_kernel(const float *part, float 
 }
 
 inline dim3 photo_grid(int B, int H, int W) { return dim3((W + TX - 1) / TX, (H + TY - 1) / TY, B); }
-inline size_t photo_lds(int C) { return (size_t)(C < PT_CC ? C : PT_CC) * PT_CAP * sizeof(float); }
+inline int photo_tile_floats(int C) { const int t = (C < PT_CC ? C : PT_CC) * PT_CAP; return t < PT_MIN_TILE ? PT_MIN_TILE : t; }
 
 int fill_photo_args(PhotoArgs &a, const float *tgt, const float *const *srcs, int V, const float *depth,
                     const float *pose, const float *K, const float *Kinv, const float *mask, int B, int C,
@@ -576,7 +583,8 @@ int dvf_photo_loss_fwd(const float *tgt, const float *const *srcs, int V, const 
     a.partials = partials;
     hipStream_t st = dvf_stream(stream);
     const dim3 grid = photo_grid(B, H, W);
-    const size_t lds = photo_lds(C);
+    a.tile_floats = photo_tile_floats(C);
+    const size_t lds = (size_t)a.tile_floats * sizeof(float);
     rc = dispatch_mode(flags, [&](auto border, auto align, auto pix) {
         constexpr bool BD = decltype(border)::value, AL = decltype(align)::value, PX = decltype(pix)::value;
         switch (V) {
@@ -615,7 +623,8 @@ int dvf_photo_loss_bwd(const float *tgt, const float *const *srcs, int V, const 
     const int64_t nblk = (int64_t)grid.x * grid.y * grid.z;
     a.pose_part = g_pose ? pose_ws + (int64_t)V * B * 12 : nullptr;
     hipStream_t st = dvf_stream(stream);
-    const size_t lds = photo_lds(C);
+    a.tile_floats = photo_tile_floats(C);
+    const size_t lds = (size_t)a.tile_floats * sizeof(float);
     rc = dispatch_mode(flags, [&](auto border, auto align, auto pix) {
         constexpr bool BD = decltype(border)::value, AL = decltype(align)::value, PX = decltype(pix)::value;
         switch (V) {

