@@ -324,6 +324,7 @@ struct WgradArgs {
     int CK, BH, lnp, tilesX, tilesY, PSPLIT;
     int PHq, PWq, PWH, RS, PS, COTP;
     int vp;              // P tile loaded in 16-byte lanes (GW % 4 == 0, 16-byte aligned base)
+    int dbg;             // ablation switches (-DDVF_TUNING builds): 1 no Q loads, 2 no P loads, 4 no MFMA, 8 no atomic epilogue, 16 no LDS stores
 };
 
 constexpr int WG_BW = 32;
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     auto issue_tile = [&](int tile) {
         int n, gy0, gx0;
         tile_origin(tile, n, gy0, gx0);
-        {   // Q patch rows wave, wave+4, ...: one 64-lane load per row (single pass: PWq <= 64)
+        if (!DVF_DBG(a, 1)) {   // Q patch rows wave, wave+4, ...: one 64-lane load per row (single pass: PWq <= 64)
             const int qy0 = gy0 * a.S - a.pad, qx0 = gx0 * a.S - a.pad;
             const unsigned cb = (unsigned)((n * a.QCtot + a.q_base + c0) * a.QH * a.QW) << 2;
             const int ix = qx0 + lane;
@@ -408,7 +409,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 }
             }
         }
-        if (a.vp) {
+        if (DVF_DBG(a, 2)) {
+        } else if (a.vp) {
             // P tile in 16-byte lanes: instruction k of this wave = image row (k' % BH) of the 8 channels 8*(k'/BH)..+7,
             // k' = wave + 4k; lane = (channel seg = lane >> 3, pixel group q = lane & 7 -> pixels 4q..4q+3).  4x fewer
             // vector-memory instructions than one float per lane: this kernel is bound by their issue rate.
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         }
     };
     auto store_tile = [&]() {
+        if (DVF_DBG(a, 16)) return;
         {
             int ci = 0, r = wave;
             while (r >= a.PHq) { r -= a.PHq; ++ci; }
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             };
             using B0 = std::integral_constant<int, 0>;
             using B1 = std::integral_constant<int, 1>;
-            const int ngroups = a.BH * 4;          // 32 pixels per row = 16 steps = 4 groups of 4 steps
+            const int ngroups = DVF_DBG(a, 4) ? 0 : a.BH * 4;          // 32 pixels per row = 16 steps = 4 groups of 4 steps
             load(B0{}, 0, 0);
             for (int gq = 0; gq < ngroups; gq += 2) {
                 load(B1{}, (gq + 1) >> 2, ((gq + 1) & 3) * 8);
@@ -600,6 +603,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         }
     }
     // ---- add the G tile: row = P channel, col = (c, tap)
+    if (DVF_DBG(a, 8)) {                                   // (keep the accumulators alive)
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < NTW; ++u)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[m][u][r];
+        if (s == 1.2345e-30f) a.G[0] = s;
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
         if (gcol[u] < 0) continue;
@@ -1150,6 +1164,7 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
         const bool pf = !no_pf && a.PWq <= 64 && cdiv(CK * a.PHq, 4) <= 24 && 8 * MT * (a.BH >> 1) <= 16 * MT;
         static const bool no_vp = dvf_tune("DVF_WG_NOVP") != nullptr;
         a.vp = (pf && !no_vp && a.GW % 4 == 0 && (reinterpret_cast<uintptr_t>(a.P) & 15) == 0) ? 1 : 0;
+        if (const char *e = dvf_tune("DVF_WG_DBG")) a.dbg = atoi(e);
         dvf_plan_note(DVF_K_WGRAD, MT, NTW, pf ? 1 : 0, CK, a.BH, psplit, a.vp, a.S, 256, (int)lds, KK);
         if (pf) {
             if (MT == 2 && NTW == 2) conv_wgrad_kernel<2, 2, true><<<grid, 256, lds, st>>>(a);

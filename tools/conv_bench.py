@@ -25,6 +25,11 @@ LAYERS = [  # name, cin segs, cout, k, s, p, op, transposed, act, (N,H,W), out_h
     ("upconv2 T3x3s2 64->32 ->128x416", [64], 32, 3, 2, 1, 1, True, 1, (4, 64, 208), None),
     ("upconv1 T3x3s2 32->16 ->256x832", [32], 16, 3, 2, 1, 1, True, 1, (4, 128, 416), None),
     ("pose up T4x4s2 128->64 ->64x208", [128], 64, 4, 2, 1, 0, True, 1, (4, 32, 104), None),
+    ("iconv7 3x3s1 1024->512 @4x13", [512, 512], 512, 3, 1, 1, 0, False, 1, (4, 4, 13), None),
+    ("iconv6 3x3s1 1024->512 @8x26", [512, 512], 512, 3, 1, 1, 0, False, 1, (4, 8, 26), None),
+    ("iconv5 3x3s1 512->256 @16x52", [256, 256], 256, 3, 1, 1, 0, False, 1, (4, 16, 52), None),
+    ("iconv3 3x3s1 129->64 @64x208", [64, 64, 1], 64, 3, 1, 1, 0, False, 1, (4, 64, 208), None),
+    ("conv7.2 3x3s1 512->512 @2x7", [512], 512, 3, 1, 1, 0, False, 1, (4, 2, 7), None),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 iters = int(os.environ.get("CB_ITERS", "10"))
