@@ -23,9 +23,7 @@ def add_common_flags(parser):
     g.add_argument("--height", type=int, default=256)
     g.add_argument("--width", type=int, default=832)
     g.add_argument("--steps-per-epoch", type=int, default=50, help="synthetic iterations per epoch")
-    g.add_argument("--align-corners", action="store_true", help="grid_sample(align_corners=True); default = what the reference runs as")
     g.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
-    g.add_argument("--sync-every", type=int, default=10, help="host sync / log interval in steps (reference: every step)")
 
 
 def init_distributed():
@@ -53,7 +51,9 @@ def save_best(output_dir, named_modules):
     """Reference file names (train.py:242-247, unsupervise.py:156-163): bare state_dicts."""
     os.makedirs(output_dir, exist_ok=True)
     for fname, module in named_modules:
-        torch.save(module.state_dict(), os.path.join(output_dir, fname))
+        # parameters are views into FlatAdam's single arena: clone, or torch.save would serialise the whole arena
+        # (every network's weights) into each file
+        torch.save({k: v.detach().cpu().clone() for k, v in module.state_dict().items()}, os.path.join(output_dir, fname))
 
 
 def run_training(args, nets, loss_fn, lr, betas, weight_decay, term_names, ckpt_names, n_views=2):
@@ -79,6 +79,15 @@ def run_training(args, nets, loss_fn, lr, betas, weight_decay, term_names, ckpt_
                 for sample in loader:
                     yield un_dataset.to_batch(sample, device)
         feed = feed()
+    KEYS = ("img_R2", "img_R1", "img_L2", "K", "Kinv", "T_R2L", "T_R2L_se3")
+
+    def load_next():
+        nxt = next(feed)
+        for k in KEYS:
+            batch[k].copy_(nxt[k].reshape(batch[k].shape), non_blocking=True)
+
+    if feed is not None:
+        load_next()              # the warm-up / capture steps below already train: they must see real data, not noise
     acc = torch.zeros(len(term_names), device=device)            # device-side running sums: no per-step .item()
 
     def step():
@@ -98,11 +107,13 @@ def run_training(args, nets, loss_fn, lr, betas, weight_decay, term_names, ckpt_
         acc.zero_()
         t0 = time.perf_counter()
         for it in range(args.steps_per_epoch):
-            if feed is not None:
-                nxt = next(feed)
-                for k in ("img_R2", "img_R1", "img_L2", "K", "Kinv", "T_R2L"):
-                    batch[k].copy_(nxt[k].reshape(batch[k].shape), non_blocking=True)
+            if feed is not None and (epoch, it) != (0, 0):
+                load_next()
             runner()
+            if getattr(args, "log_interval", 0) and rank == 0 and (it + 1) % args.log_interval == 0:
+                # (one host sync per log interval; the reference syncs on five .item() calls every step, train.py:205-209)
+                print(f"  epoch {epoch} [{it + 1}/{args.steps_per_epoch}] {term_names[0]}: "
+                      f"{float(acc[0]) / (it + 1):.6f}", flush=True)
             # a fresh synthetic batch every step would only change values, not the work; new data is copied into the
             # static input tensors in place (graph replay reads the same addresses)
         torch.cuda.synchronize()

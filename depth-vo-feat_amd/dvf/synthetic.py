@@ -21,5 +21,7 @@ def synthetic_batch(b, h, w, seed=1234, rank=0, n_views=2, smooth_images=True, d
     out = {"img_R2": imgs[0], "img_R1": imgs[1], "img_L2": imgs[2] if n_views >= 2 else imgs[1],
            "extra_refs": imgs[3:], "K": K.float().expand(b, 3, 3).contiguous(),
            "Kinv": Kinv.float().expand(b, 3, 3).contiguous(),
-           "T_R2L": torch.tensor([-0.54, 0, 0, 0, 0, 0], dtype=torch.float32).expand(b, 6).contiguous()}
+           "T_R2L": torch.tensor([-0.54, 0, 0, 0, 0, 0], dtype=torch.float32).expand(b, 6).contiguous(),
+           # the same stereo pose as the reference dataset stores it: se(3) order (w, u)  (data/dataset_builder.py:155)
+           "T_R2L_se3": torch.tensor([0, 0, 0, -0.54, 0, 0], dtype=torch.float32).expand(b, 6).contiguous()}
     return {k: ([t.to(device) for t in v] if isinstance(v, list) else v.to(device)) for k, v in out.items()}

@@ -95,8 +95,32 @@ class dataset(data.Dataset):
         return len(self.samples)
 
 
+def se3_to_tr_euler(se3):
+    """Stereo pose file convention -> pose_vec2mat convention.  The reference's dataset stores T_R2L as the se(3)
+    vector (wx, wy, wz, ux, uy, uz) = (0, 0, 0, Tx, 0, 0) (data/dataset_builder.py:155; consumed as such by the
+    Caffe-style chain, unsupervise_dvo.py:98-100 -> se3_generate.py: R = exp([w]x), t = R u).  inverse_warp.py's
+    pose_vec2mat wants (tx, ty, tz, rx, ry, rz) with R = Rx Ry Rz (inverse_warp.py:77-114, :141-157).  Exact
+    conversion through the rotation matrix (for the rectified stereo rig w = 0, so this is t = u, r = 0)."""
+    w, u = se3[:, :3].double(), se3[:, 3:6].double()
+    th = w.norm(dim=1, keepdim=True)
+    k = torch.where(th > 1e-12, w / th.clamp_min(1e-300), torch.zeros_like(w))
+    K = torch.zeros(se3.shape[0], 3, 3, dtype=torch.float64, device=se3.device)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -k[:, 2], k[:, 1], k[:, 2], -k[:, 0], -k[:, 1], k[:, 0]
+    I = torch.eye(3, dtype=torch.float64, device=se3.device).expand_as(K)
+    s, c = torch.sin(th)[..., None], torch.cos(th)[..., None]
+    R = I + s * K + (1 - c) * (K @ K)                                   # Rodrigues
+    t = (R @ u[..., None])[..., 0]
+    ry = torch.asin(R[:, 0, 2].clamp(-1, 1))                            # R = Rx Ry Rz: R02 = sin(ry)
+    rz = torch.atan2(-R[:, 0, 1], R[:, 0, 0])
+    rx = torch.atan2(-R[:, 1, 2], R[:, 2, 2])
+    return torch.cat((t, torch.stack((rx, ry, rz), dim=1)), dim=1).to(se3.dtype)
+
+
 def to_batch(sample_batch, device):
-    """Collated dataset output -> the batch dict of dvf/steps.py (device tensors)."""
+    """Collated dataset output -> the batch dict of dvf/steps.py (device tensors).  The stereo pose is provided in BOTH
+    conventions: ``T_R2L_se3`` as the files hold it (w, u) for unsupervise_dvo.py, and ``T_R2L`` converted to the
+    (t, r-euler) order of pose_vec2mat for unsupervise.py / train.py -- the two APIs must never see each other's."""
     r1, l2, r2, K, Kinv, raw_K, T = [x.to(device, non_blocking=True) for x in sample_batch]
+    se3 = T.reshape(T.shape[0], -1)[:, :6].contiguous()
     return {"img_R1": r1.contiguous(), "img_L2": l2.contiguous(), "img_R2": r2.contiguous(), "K": K.contiguous(),
-            "Kinv": Kinv.contiguous(), "raw_K": raw_K, "T_R2L": T.reshape(T.shape[0], -1)[:, :6].contiguous()}
+            "Kinv": Kinv.contiguous(), "raw_K": raw_K, "T_R2L_se3": se3, "T_R2L": se3_to_tr_euler(se3).contiguous()}

@@ -55,8 +55,10 @@ def main():
         n.to(args._device).train()
 
     def loss_fn(batch):
+        # this script's chain consumes the stereo pose in se(3) order (w, u), exactly as the dataset files hold it
+        # (data/dataset_builder.py:155); both the synthetic stream and un_dataset.to_batch provide it under this key
         b = dict(batch)
-        b["T_R2L"] = batch["T_R2L"][:, [3, 4, 5, 0, 1, 2]].contiguous()   # (t, r) recipe -> se(3) order (w, u)
+        b["T_R2L"] = batch["T_R2L_se3"]
         return unsupervise_dvo_losses(depth_net, odometry_net, b)
 
     cli.run_training(args, [odometry_net, depth_net], loss_fn, args.lr, (0.9, 0.999), args.weight_decay,

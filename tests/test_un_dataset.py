@@ -31,7 +31,9 @@ def _make_tree(tmp_path, n=3):
                 paths.append(str(p))
             kid = f"{drive[-9:-5]}_{i}"
             np.save(root / "train_K" / (kid + ".npy"), K.astype(np.float64))
-            np.save(root / "train_T_R2L" / (kid + ".npy"), np.array([[-0.54, 0, 0, 0, 0, 0]]))
+            # the reference's builder writes the stereo pose as an se(3) vector (w, u) = (0, 0, 0, Tx, 0, 0)
+            # (data/dataset_builder.py:155)
+            np.save(root / "train_T_R2L" / (kid + ".npy"), np.array([[0, 0, 0, -0.54, 0, 0]]))
             lines.append(" ".join(paths + [kid, kid]))
     (root / "train.txt").write_text("\n".join(lines) + "\n")
     return root
@@ -46,7 +48,7 @@ def test_dataset_samples_and_resize_semantics(tmp_path):
         assert t.dtype == torch.float32 and tuple(t.shape) == (3, 16, 48)
         assert float(t.min()) >= 0 and float(t.max()) <= 255
     assert torch.allclose(K @ Kinv, torch.eye(3), atol=1e-3)      # (fp32 inverse, as in the reference)
-    assert tuple(raw_K.shape) == (3, 3) and tuple(T.shape) == (1, 6) and float(T[0, 0]) == np.float32(-0.54)
+    assert tuple(raw_K.shape) == (3, 3) and tuple(T.shape) == (1, 6) and float(T[0, 3]) == np.float32(-0.54)
     # the resize is PIL's bilinear on the byte-scaled image
     src = un_dataset.imread(ds.samples[1]["right_1"]).astype(np.float32)
     lo, hi = src.min(), src.max()
@@ -64,3 +66,23 @@ def test_loader_and_batch_dict(tmp_path):
     batch = un_dataset.to_batch(next(iter(loader)), "cpu")
     assert tuple(batch["img_R2"].shape) == (2, 3, 16, 48) and tuple(batch["K"].shape) == (2, 3, 3)
     assert tuple(batch["T_R2L"].shape) == (2, 6) and batch["img_L2"].is_contiguous()
+    # the stereo baseline reaches each API in ITS convention: se(3) (w, u) as stored for unsupervise_dvo.py,
+    # (t, r-euler) for pose_vec2mat (unsupervise.py / train.py) -- a 0.54 m translation along x in both, no rotation
+    assert torch.equal(batch["T_R2L_se3"], torch.tensor([[0, 0, 0, -0.54, 0, 0]] * 2))
+    assert torch.allclose(batch["T_R2L"], torch.tensor([[-0.54, 0, 0, 0, 0, 0]] * 2), atol=1e-7)
+
+
+def test_se3_to_tr_euler_is_the_same_rigid_motion():
+    """General case (w != 0): exp-map pose [R | R u] (se3_generate.py:13-47) == pose_vec2mat of the converted vector."""
+    from oracle import geometry as og
+    g = torch.Generator().manual_seed(5)
+    se3 = torch.randn(6, 6, generator=g) * 0.3
+    se3[0, :3] = 0
+    tr = un_dataset.se3_to_tr_euler(se3)
+    want = og.se3_exp(se3.double())                          # [n, 3, 4]
+    got = og.pose_vec2mat(tr.double(), "euler")
+    assert torch.allclose(got, want, atol=1e-6)
+    # and the synthetic stream carries the same pose under both keys
+    from dvf.synthetic import synthetic_batch
+    b = synthetic_batch(2, 8, 16)
+    assert torch.allclose(un_dataset.se3_to_tr_euler(b["T_R2L_se3"]), b["T_R2L"], atol=1e-7)
