@@ -47,6 +47,7 @@ struct PhotoArgs {
     float in_scale;
     int vec;                       // sources may be staged in 16-byte lanes (W % 4 == 0, 16-byte aligned bases)
     int tile_floats;               // size of the dynamic LDS tile
+    int caffe;                     // DVF_CAFFE_ABSLOSS: per-sample sum, no exact-zero mask, sign(0) -> one side
     int dbg;                       // ablation switches (-DDVF_TUNING builds only): 1 no pass 2, 2 no flush atomics, 4 no LDS adds, 8 no staging, 16 no LDS tiles at all
 };
 
@@ -113,6 +114,7 @@ __device__ __forceinline__ Foot footprint(const TapPos &p, int vec, int (*bbs)[4
     const int fp = f.RS * f.rows;
     f.cc = (x1 < 0 || fp <= 0) ? 0 : min(PT_CC, tile_floats / fp);
     f.mode = (x1 < 0) ? 0 : ((f.cc >= 1 && f.RS <= 256 && !force_direct) ? 1 : 2);
+    if (x1 < 0) { f.xlo = f.ylo = 0; f.RS = f.rows = 1; }   // (no valid tap anywhere: callers that still walk the channels read zeros)
     return f;
 }
 
@@ -225,8 +227,8 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(PhotoArgs a) {
         const TapPos tp = tap_pos(s, W, H, inside);
         const Foot f = footprint(tp, a.vec, bbs, a.tile_floats, DVF_DBG(a, 16));
         float acc = 0.f;
-        bool nz = false;
-        if (f.mode != 0) {                                  // (mode 0: no pixel of the block samples inside this source)
+        bool nz = a.caffe != 0;                             // (Caffe AbsLoss: no exact-zero validity mask)
+        if (f.mode != 0 || a.caffe) {                       // (mode 0: no pixel of the block samples inside this source)
             const TileOff o = tile_off(tp, f);
             const int chs = f.rows * f.RS;
             const int cstep = f.mode == 1 ? f.cc : PT_CC;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(PhotoArgs a) {
                     if (!DVF_DBG(a, 8)) stage_tile(tile, a.src[vi], f, b, C, c0, nch, H, W, a.in_scale, a.vec, tid);
                     __syncthreads();
                 }
-                if (!tp.any) continue;                      // warped == 0 in every channel: nz stays false
+                if (!tp.any && !a.caffe) continue;          // warped == 0 in every channel: nz stays false
                 const float *sp = a.src[vi] + ((int64_t)b * C + c0) * HW;
 #pragma unroll 1
                 for (int k0 = 0; k0 < nch; k0 += 4) {       // four channels at a time
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
     const int HW = H * W;
     const bool inside = x < W && y < H;
     const int pix = min(y, H - 1) * W + min(x, W - 1);
-    const float scale = a.grad_loss[0] / ((float)a.B * (float)C * (float)H * (float)W);
+    const float scale = a.caffe ? a.grad_loss[0] / (float)a.B : a.grad_loss[0] / ((float)a.B * (float)C * (float)H * (float)W);
     const float d = a.depth[(int64_t)b * HW + pix];
     const float u = (float)x, v = (float)y;
     const float c0x = kinv[0] * u + kinv[1] * v + kinv[2];
@@ -338,8 +340,8 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
         const float m = a.mask ? a.mask[((int64_t)b * NV + vi) * HW + pix] : 1.f;
         float gix = 0.f, giy = 0.f, absum = 0.f;
         uint32_t lo = 0u, hi = 0u;
-        bool nzf = false;
-        if (f.mode != 0) {
+        bool nzf = a.caffe != 0;
+        if (f.mode != 0 || a.caffe) {
             const TileOff o = tile_off(tp, f);
             const int chs = f.rows * f.RS;
             const int cstep = f.mode == 1 ? f.cc : PT_CC;
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
                     if (!DVF_DBG(a, 8)) stage_tile(tile, a.src[vi], f, b, C, c0, nch, H, W, a.in_scale, a.vec, tid);
                     __syncthreads();
                 }
-                if (!tp.any) continue;
+                if (!tp.any && !a.caffe) continue;
                 const float *sp = a.src[vi] + ((int64_t)b * C + c0) * HW;
 #pragma unroll 1
                 for (int k0 = 0; k0 < nch; k0 += 4) {
@@ -368,7 +370,9 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
                             const float wv = blend(t, s);
                             nzf |= (wv != 0.f);
                             const float df = tv[j] - wv;
-                            const float sg = sgn(df * m);   // sign of the masked difference
+                            // sign of the masked difference; Caffe AbsLoss: (warped - tgt > 0) - (warped - tgt <= 0), i.e. a
+                            // zero difference counts as tgt >= warped                     abs_loss_layer.cu:31
+                            const float sg = a.caffe ? ((df * m >= 0.f) ? 1.f : -1.f) : sgn(df * m);
                             absum += fabsf(df);
                             float dox, doy;
                             blend_grad(t, s, dox, doy);
@@ -555,6 +559,7 @@ int fill_photo_args(PhotoArgs &a, const float *tgt, const float *const *srcs, in
     a.B = B; a.C = C; a.H = H; a.W = W; a.V = V;
     a.quat = rot_mode(flags);
     a.in_scale = in_scale;
+    a.caffe = (flags & DVF_CAFFE_ABSLOSS) ? 1 : 0;
     if (const char *e = dvf_tune("DVF_PHOTO_DBG")) a.dbg = atoi(e);
     return DVF_OK;
 }
@@ -597,7 +602,7 @@ int dvf_photo_loss_fwd(const float *tgt, const float *const *srcs, int V, const 
         return DVF_OK;
     });
     if (rc != DVF_OK) return rc;
-    const float inv_n = 1.f / ((float)B * (float)C * (float)H * (float)W);
+    const float inv_n = (flags & DVF_CAFFE_ABSLOSS) ? 1.f / (float)B : 1.f / ((float)B * (float)C * (float)H * (float)W);
     photo_reduce_kernel<<<1, 256, 0, st>>>(partials, (int64_t)grid.x * grid.y * grid.z, V, inv_n, loss_out, view_loss);
     DVF_LAUNCH_CHECK();
     return DVF_OK;

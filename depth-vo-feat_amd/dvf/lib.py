@@ -32,7 +32,7 @@ class ConvDesc(ctypes.Structure):
 c_desc = ctypes.POINTER(ConvDesc)
 c_ip = ctypes.POINTER(ctypes.c_int)
 
-ROT_QUAT, PAD_BORDER, ALIGN_CORNERS, POSE_SE3, PIXEL_COORDS = 1, 2, 4, 8, 16
+ROT_QUAT, PAD_BORDER, ALIGN_CORNERS, POSE_SE3, PIXEL_COORDS, CAFFE_ABSLOSS = 1, 2, 4, 8, 16, 32
 ACT_NONE, ACT_RELU, ACT_SIGMOID_AFFINE = 0, 1, 2
 MAX_VIEWS, MAX_SEGS = 4, 5
 
@@ -55,6 +55,9 @@ SIGNATURES = {
     "dvf_photo_partials_floats": (c_i64, [c_i] * 4),
     "dvf_photo_pose_ws_floats": (c_i64, [c_i] * 4),
     "dvf_photo_loss_bwd": (c_i, [c_fp, c_pp, c_i] + [c_fp] * 9 + [c_pp, c_fp, c_fp] + [c_i] * 4 + [c_f, c_u32, c_fp]),
+    "dvf_edge_smooth_fwd": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_f, c_i, c_fp]),
+    "dvf_edge_smooth_partials_floats": (c_i64, [c_i] * 3),
+    "dvf_edge_smooth_bwd": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_f, c_fp]),
     "dvf_smooth_loss_fwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_f, c_i, c_fp]),
     "dvf_smooth_partials_floats": (c_i64, [c_i] * 3),
     "dvf_smooth_loss_bwd": (c_i, [c_fp] * 3 + [c_i] * 3 + [c_f, c_fp]),

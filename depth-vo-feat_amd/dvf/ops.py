@@ -139,6 +139,36 @@ class SmoothLossFn(torch.autograd.Function):
         return (None, *grads)
 
 
+class EdgeSmoothLossFn(torch.autograd.Function):
+    """Edge-aware first-order smoothness of the inverse depth as the reference's Caffe graph defines it
+    (experiments/depth_odometry_feature/train.prototxt:4452-4661): see csrc/paper_losses.hip."""
+
+    @staticmethod
+    def forward(ctx, inv_depth, img, in_scale, edge_k, weight):
+        inv_depth, img = _f32c(inv_depth), _f32c(img)
+        B, C, H, W = img.shape
+        if tuple(inv_depth.shape) not in ((B, 1, H, W), (B, H, W)):
+            raise ValueError(f"inv_depth {tuple(inv_depth.shape)} does not match image {tuple(img.shape)}")
+        lib = L.lib()
+        out = torch.empty(1, device=img.device)
+        partials = torch.empty(int(lib.dvf_edge_smooth_partials_floats(B, H, W)), device=img.device)
+        L.check(lib.dvf_edge_smooth_fwd(L.dev(inv_depth, "inv_depth"), L.dev(img, "img"), L.dev(out), L.dev(partials), B, C, H, W,
+                                        in_scale, edge_k, weight, 0, L.stream()), "dvf_edge_smooth_fwd")
+        ctx.save_for_backward(inv_depth, img)
+        ctx.cfg = (in_scale, edge_k, weight)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        inv_depth, img = ctx.saved_tensors
+        B, C, H, W = img.shape
+        g = torch.empty_like(inv_depth)
+        in_scale, edge_k, weight = ctx.cfg
+        L.check(L.lib().dvf_edge_smooth_bwd(L.dev(inv_depth), L.dev(img), L.dev(_f32c(gloss).reshape(1), "grad_loss"), L.dev(g),
+                                            B, C, H, W, in_scale, edge_k, weight, L.stream()), "dvf_edge_smooth_bwd")
+        return g, None, None, None, None
+
+
 class ExplainabilityLossFn(torch.autograd.Function):
     """explainability_loss over a list of masks (reference loss_functions_sfm.py:49-56)."""
 

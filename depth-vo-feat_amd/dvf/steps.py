@@ -123,3 +123,32 @@ def unsupervise_dvo_losses(depth_net, pose_net, batch, img_scale=0.004, smooth_w
     smooth = LF.smooth_loss(depth)
     loss = photo + smooth_weight * smooth
     return loss, {"photo": photo.detach(), "smooth": smooth.detach(), "total": loss.detach()}
+
+
+def paper_losses(depth_net, pose_net, batch, feat_extractor=None, img_scale=0.004, smooth_weight=10.0, feat_weight=0.1,
+                 depth_eps=1e-4):
+    """The loss of the reference's Caffe experiment ``depth_odometry_feature`` (train.prototxt:4355-4367, 4428-4446,
+    4452-4661, 5571-5588): AbsLoss warp errors of the left and of the previous right image under the
+    se(3) / pixel-coordinate chain (weight 1 each), edge-aware first-order smoothness of the inverse depth (weight 10)
+    and, with ``feat_extractor`` (frozen: its parameters must not require gradients), 0.1 * AbsLoss on warped
+    feature maps.  batch["T_R2L_se3"] is the stereo pose as the dataset holds it."""
+    import loss_functions_caffe as LC
+    R2, R1, L2 = batch["img_R2"], batch["img_R1"], batch["img_L2"]
+    (_, T_2to1), disps = _side_by_side(lambda: pose_net((R2, R1)), lambda: depth_net(R2))
+    inv_depth = disps[0]
+    depth = reciprocal(inv_depth, depth_eps)                               # depth = (inv_depth + 1e-4)^-1  (:4355-4367)
+    poses = (batch["T_R2L_se3"], T_2to1)
+    photo = LC.abs_warp_loss(R2, (L2, R1), depth, poses, batch["K"], batch["Kinv"], img_scale=img_scale)
+    smooth = LC.edge_aware_smooth_loss(inv_depth, R2, img_scale=img_scale)
+    loss = photo + smooth_weight * smooth
+    terms = {"photo": photo.detach(), "smooth": smooth.detach()}
+    if feat_extractor is not None:
+        b = R2.size(0)
+        with torch.no_grad():                                              # frozen extractor: no graph, no weight gradients
+            feat = feat_extractor(torch.cat((L2, R2, R1), dim=0))
+        f_L2, f_R2, f_R1 = feat[:b], feat[b:2 * b], feat[2 * b:]
+        lf = LC.abs_warp_loss(f_R2, (f_L2, f_R1), depth, poses, batch["K"], batch["Kinv"])
+        loss = loss + feat_weight * lf
+        terms["feat"] = lf.detach()
+    terms["total"] = loss.detach()
+    return loss, terms

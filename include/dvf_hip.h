@@ -40,6 +40,10 @@ extern "C" {
                                 overwrite and no depth clamp: Caffe GeoTransform -> PinHole -> InverseWarping semantics
                                 (geometry_transformation.cu:10-47, pin_hole_layer.cu:10-50, inverse_warping_layer.cu:10-52) */
 
+#define DVF_CAFFE_ABSLOSS 32u /* photometric loss normalised and differentiated like Caffe's AbsLoss (abs_loss_layer.cu:10-34,
+                                experiments/depth_odometry_feature/train.prototxt:4428-4446): sum |warped - target| / B (per-sample
+                                sum, not a mean), NO exact-zero validity mask, d|d|/dd = (d > 0) - (d <= 0) */
+
 /* activation codes for the convolution epilogues */
 #define DVF_ACT_NONE 0
 #define DVF_ACT_RELU 1
@@ -124,6 +128,17 @@ int dvf_photo_loss_bwd(const float *tgt, const float *const *srcs, int V, const 
                        float *const *g_srcs, float *g_mask, float *pose_ws, int B, int C, int H, int W,
                        float in_scale, uint32_t flags, void *stream);
 int64_t dvf_photo_pose_ws_floats(int B, int H, int W, int V);
+
+/* ---------------------------------------------------------------- edge-aware smoothness (paper / Caffe graph variant)
+ * experiments/depth_odometry_feature/train.prototxt:4452-4661 with caffe/include/caffe/filler.hpp:267-316 and
+ * abs_loss_layer.cu:10-34: loss_out[0] (+)= weight * (sum |exp(-k sum_c |d_y I_c|) d_y D| + sum |exp(-k sum_c |d_x I_c|) d_x D|) / B
+ * over the (H-2) x (W-2) interior (3x3 valid central differences, +-0.5), I = in_scale * img [B,C,H,W], D = inv_depth [B,H,W];
+ * backward writes g_inv_depth [B,H,W] (AbsLoss sign convention: zero counts as positive).  Parity unpinned (no Caffe here). */
+int dvf_edge_smooth_fwd(const float *inv_depth, const float *img, float *loss_out, float *partials, int B, int C, int H, int W,
+                        float in_scale, float edge_k, float weight, int accumulate, void *stream);
+int64_t dvf_edge_smooth_partials_floats(int B, int H, int W);
+int dvf_edge_smooth_bwd(const float *inv_depth, const float *img, const float *grad_loss, float *g_inv_depth, int B, int C, int H,
+                        int W, float in_scale, float edge_k, float weight, void *stream);
 
 /* ---------------------------------------------------------------- smoothness loss
  * Replaces one map of smooth_loss (loss_functions.py:23-41 ; loss_functions_sfm.py:59-77):

@@ -210,12 +210,18 @@ def inverse_warp_pixel(img, depth, T, K):
     return out
 
 
-def dvo_photometric_loss(img_R2, img_L2, img_R1, depth, T_R2L, T_2to1, K):
+def dvo_photometric_loss(img_R2, img_L2, img_R1, depth, T_R2L, T_2to1, K, caffe_abs=False):
     """LR_error + R12_error of unsupervise_dvo.py:96-117: se3 exp-map poses, pixel-coordinate warps of the left image
-    (stereo pose) and of the previous right image (temporal pose), exact-zero mask, L1 mean each."""
+    (stereo pose) and of the previous right image (temporal pose), exact-zero mask, L1 mean each.
+    caffe_abs: the Caffe graph's form instead (train.prototxt:4428-4446): AbsLoss(warped, target) -- per-sample sum,
+    no validity mask, AbsLoss's sign convention."""
+    from .losses import abs_loss_caffe
     loss = 0
     for src, pose in ((img_L2, T_R2L), (img_R1, T_2to1)):
         warped = inverse_warp_pixel(src, depth, se3_exp(pose), K)
+        if caffe_abs:
+            loss = loss + abs_loss_caffe(warped, img_R2)
+            continue
         valid = 1 - (warped == 0).prod(1, keepdim=True).type_as(warped)
         loss = loss + ((img_R2 - warped) * valid).abs().mean()
     return loss

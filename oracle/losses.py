@@ -95,3 +95,42 @@ def explainability_loss(mask):
     for m in mask:
         loss = loss + (-torch.clamp(torch.log(m), min=-100.0)).mean()
     return loss
+
+
+# ----------------------------------------------------------------------------- paper-faithful variants (Caffe graph)
+class _CaffeAbsSum(torch.autograd.Function):
+    """sum |v| with AbsLoss's backward convention: d|v|/dv = (v > 0) - (v <= 0) applied to diff = bottom0 - bottom1
+    (caffe/src/caffe/layers/abs_loss_layer.cu:28-34) -- an exact zero gets a gradient of -1 w.r.t. `diff`, not 0."""
+
+    @staticmethod
+    def forward(ctx, diff):
+        ctx.save_for_backward(diff)
+        return diff.abs().sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (diff,) = ctx.saved_tensors
+        return g * torch.where(diff > 0, torch.ones_like(diff), -torch.ones_like(diff))
+
+
+def abs_loss_caffe(bottom0, bottom1):
+    """Caffe AbsLoss (abs_loss_layer.cu:10-26): sum |bottom0 - bottom1| / N with N = bottom0.num() (the batch size) --
+    a per-sample SUM, not a mean -- and the sign convention above.  No validity mask: the Caffe graph has none
+    (experiments/depth_odometry_feature/train.prototxt:4428-4446)."""
+    return _CaffeAbsSum.apply(bottom0 - bottom1) / bottom0.shape[0]
+
+
+def edge_aware_smooth_caffe(inv_depth, img, edge_k=0.33):
+    """Edge-aware first-order smoothness of the inverse depth, train.prototxt:4452-4661 (without its loss_weight 10):
+    3x3 VALID cross-correlations with the EdgeX / EdgeY fillers (caffe/include/caffe/filler.hpp:267-316: EdgeX is the
+    central difference along y, EdgeY along x, both with +-0.5), image edges |.| summed over channels with -0.33,
+    exp(), product with the inverse-depth differences, AbsLoss against zeros (bottom0 = 0, bottom1 = dx)."""
+    c = img.shape[1]
+    ex = img.new_tensor([[0, -0.5, 0], [0, 0, 0], [0, 0.5, 0]]).view(1, 1, 3, 3)
+    ey = img.new_tensor([[0, 0, 0], [-0.5, 0, 0.5], [0, 0, 0]]).view(1, 1, 3, 3)
+    gx = torch.exp(-edge_k * F.conv2d(img, ex.expand(c, 1, 3, 3), groups=c).abs().sum(1, keepdim=True))
+    gy = torch.exp(-edge_k * F.conv2d(img, ey.expand(c, 1, 3, 3), groups=c).abs().sum(1, keepdim=True))
+    dx = gx * F.conv2d(inv_depth, ex)
+    dy = gy * F.conv2d(inv_depth, ey)
+    zeros = torch.zeros_like(dx)
+    return abs_loss_caffe(zeros, dx) + abs_loss_caffe(zeros, dy)

@@ -200,3 +200,33 @@ def step_train_sfm(disp_sd, pose_sd, batch, adam_state=None, lr=2e-4, w1=1.0, w2
                 adam_step(upd, grads[g], sub, lr, weight_decay=0.0)
                 st["step"] = sub["step"]
     return out, grads, adam_state
+
+
+def step_paper(disp_sd, pose_sd, batch, feat_sd=None, img_scale=0.004, smooth_weight=10.0, feat_weight=0.1):
+    """The Caffe experiment's loss (depth_odometry_feature/train.prototxt) on the PyTorch networks:
+    AbsLoss warp errors (se3 / pixel-coordinate chain) + 10 * edge-aware smoothness (+ 0.1 * feature AbsLoss with a
+    frozen extractor).  Gradients only (no update); batch["T_R2L_se3"] in (w, u) order."""
+    from . import geometry
+    dsd, psd = _leaf(disp_sd), _leaf(pose_sd)
+    R2, R1, L2 = batch["img_R2"], batch["img_R1"], batch["img_L2"]
+    inv_depth = nets.dispnet_forward(dsd, R2)[0]
+    _, T_2to1 = nets.posenet_forward(psd, torch.cat((R2, R1), 1), 2, True, sfm=False)
+    depth = (1 / (inv_depth + 1e-4)).squeeze(1)
+    photo = geometry.dvo_photometric_loss(img_scale * R2, img_scale * L2, img_scale * R1, depth, batch["T_R2L_se3"], T_2to1,
+                                          batch["K"], caffe_abs=True)
+    smooth = losses.edge_aware_smooth_caffe(inv_depth, img_scale * R2)
+    total = photo + smooth_weight * smooth
+    out = {"photo": photo.detach(), "smooth": smooth.detach()}
+    if feat_sd is not None:
+        b = R2.shape[0]
+        with torch.no_grad():
+            feat = nets.featnet_forward(feat_sd, torch.cat((L2, R2, R1), 0))
+        f_L2, f_R2, f_R1 = feat[:b], feat[b:2 * b], feat[2 * b:]
+        lf = geometry.dvo_photometric_loss(f_R2, f_L2, f_R1, depth, batch["T_R2L_se3"], T_2to1, batch["K"], caffe_abs=True)
+        total = total + feat_weight * lf
+        out["feat"] = lf.detach()
+    out["total"] = total.detach()
+    total.backward()
+    grads = {"disp": {k: v.grad for k, v in dsd.items() if v.grad is not None},
+             "pose": {k: v.grad for k, v in psd.items() if v.grad is not None}}
+    return out, grads

@@ -1,0 +1,124 @@
+"""SURVEY.md section 8 f-4, the losses of the reference's Caffe graph (experiments/depth_odometry_feature/train.prototxt).
+Caffe cannot run in the build image: PARITY UNPINNED.  CPU part: the oracle's restatement of AbsLoss and of the
+edge-aware smoothness against finite differences and hand-computed values.  GPU part (-m gpu): the HIP kernels against
+that oracle at 1e-4."""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import geometry as og
+from oracle import losses as ol
+
+
+def test_abs_loss_caffe_semantics():
+    a = torch.tensor([[1.0, 2.0, 3.0], [0.0, 5.0, 1.0]], dtype=torch.float64, requires_grad=True)
+    b = torch.tensor([[1.0, 0.0, 5.0], [2.0, 5.0, 0.0]], dtype=torch.float64, requires_grad=True)
+    l = ol.abs_loss_caffe(a, b)
+    assert float(l) == (0 + 2 + 2 + 2 + 0 + 1) / 2                  # per-sample SUM: / batch, not / count
+    l.backward()
+    # d/d bottom0 = ((d > 0) - (d <= 0)) / N with d = a - b: zeros take the -1 side   (abs_loss_layer.cu:31)
+    assert torch.equal(a.grad, torch.tensor([[-1.0, 1.0, -1.0], [-1.0, -1.0, 1.0]], dtype=torch.float64) / 2)
+    assert torch.equal(b.grad, -a.grad)
+
+
+def test_edge_aware_smoothness_oracle():
+    g = torch.Generator().manual_seed(0)
+    D = (torch.rand(2, 1, 9, 11, generator=g, dtype=torch.float64) * 3).requires_grad_(True)
+    I = torch.rand(2, 3, 9, 11, generator=g, dtype=torch.float64)
+    assert torch.autograd.gradcheck(lambda d: ol.edge_aware_smooth_caffe(d, I), (D,), eps=1e-6, atol=1e-5)
+    # hand-computed: a 3x3 map has ONE interior output; EdgeX differences along y, EdgeY along x (filler.hpp:267-316)
+    d = torch.tensor([[[[0.0, 2.0, 0.0], [1.0, 0.0, 5.0], [0.0, 8.0, 0.0]]]], dtype=torch.float64)
+    im = torch.tensor([[[[0.0, 1.0, 0.0], [3.0, 0.0, 7.0], [0.0, 2.0, 0.0]]]], dtype=torch.float64)
+    want = torch.exp(torch.tensor(-0.33 * 0.5, dtype=torch.float64)) * 3.0 + torch.exp(torch.tensor(-0.33 * 2.0, dtype=torch.float64)) * 2.0
+    assert abs(float(ol.edge_aware_smooth_caffe(d, im)) - float(want)) < 1e-12
+    # a constant inverse depth costs nothing, and AbsLoss's sign convention still sends a gradient (zero counts positive)
+    c = torch.full((1, 1, 6, 7), 2.5, dtype=torch.float64, requires_grad=True)
+    l = ol.edge_aware_smooth_caffe(c, torch.rand(1, 3, 6, 7, generator=g, dtype=torch.float64))
+    l.backward()
+    assert float(l) == 0.0 and float(c.grad.abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,c,h,w", [(2, 3, 37, 75), (1, 3, 128, 416)])
+def test_edge_smooth_kernel_vs_oracle(b, c, h, w):
+    import loss_functions_caffe as LC
+    g = torch.Generator().manual_seed(h)
+    D = torch.rand(b, 1, h, w, generator=g) * 3 + 0.01
+    I = torch.rand(b, c, h, w, generator=g) * 255
+    rd = D.clone().requires_grad_(True)
+    ref = ol.edge_aware_smooth_caffe(rd, 0.004 * I)
+    ref.backward()
+    gd = D.clone().cuda().requires_grad_(True)
+    out = LC.edge_aware_smooth_loss(gd, I.cuda(), img_scale=0.004)
+    out.backward()
+    assert rel_err(out, ref) < 1e-4
+    assert rel_err(gd.grad, rd.grad) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", [3, 32])
+def test_caffe_abs_warp_loss_vs_oracle(c):
+    """AbsLoss warp errors under the se(3) / pixel-coordinate chain: per-sample sum, no validity mask (out-of-view
+    pixels contribute |target|), gradients to depth, both poses and -- for feature maps -- target and sources."""
+    import loss_functions_caffe as LC
+    b, h, w = 2, 40, 96
+    g = torch.Generator().manual_seed(c)
+    smooth = lambda x: torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (2, 2, 2, 2), mode="reflect"), 5, 1)
+    tgt, s0, s1 = (smooth(torch.rand(b, c, h, w, generator=g)) for _ in range(3))
+    depth = torch.rand(b, h, w, generator=g) * 10 + 3
+    T0 = torch.tensor([[0, 0, 0, -0.54, 0, 0.0]]).expand(b, 6).contiguous() + torch.randn(b, 6, generator=g) * 0.002
+    T1 = torch.randn(b, 6, generator=g) * 0.01
+    K = torch.tensor([[0.58 * w, 0, 0.5 * w], [0, 1.92 * h, 0.5 * h], [0, 0, 1.0]]).expand(b, 3, 3).contiguous()
+    Kinv = torch.inverse(K[0]).expand(b, 3, 3).contiguous()
+    feat = c > 3
+    cpu = [x.clone().requires_grad_(True) for x in (depth, T0, T1)] + [x.clone().requires_grad_(feat) for x in (tgt, s0, s1)]
+    ref = og.dvo_photometric_loss(cpu[3], cpu[4], cpu[5], cpu[0], cpu[1], cpu[2], K, caffe_abs=True)
+    ref.backward()
+    gpu = [x.detach().cuda().requires_grad_(x.requires_grad) for x in cpu]
+    out = LC.abs_warp_loss(gpu[3], (gpu[4], gpu[5]), gpu[0], (gpu[1], gpu[2]), K.cuda(), Kinv.cuda())
+    out.backward()
+    assert rel_err(out, ref) < 1e-4
+    # masked reference for comparison: the Caffe form must be LARGER (out-of-view pixels count) and scaled by C*H*W
+    masked = og.dvo_photometric_loss(tgt, s0, s1, depth, T0, T1, K)
+    assert float(ref) > float(masked) * c * h * w
+    for name, a, r in zip(("depth", "T_R2L", "T_2to1", "tgt", "src0", "src1"), gpu, cpu):
+        if r.grad is not None:
+            # (per-pixel gradients of a bilinear sampler flip where a coordinate crosses an integer: bound the count)
+            bad = ((a.grad.cpu() - r.grad).abs() > 1e-4 * float(r.grad.abs().max())).sum()
+            assert int(bad) <= 2e-3 * r.grad.numel() + (2 if name.startswith("T") else 0), (name, int(bad))
+
+
+@pytest.mark.gpu
+def test_paper_step_vs_oracle():
+    """The whole depth_odometry_feature loss (AbsLoss warps + 10 * edge-aware smoothness + 0.1 * frozen-feature AbsLoss)
+    through the three networks against the oracle's composition; the frozen extractor receives no gradient."""
+    import DispNetS
+    import PoseExpNet
+    import feat_extractor
+    from dvf.steps import paper_losses
+    from dvf.synthetic import synthetic_batch
+    from oracle import nets as onets
+    from oracle import steps as osteps
+    b, h, w = 2, 64, 128
+    dsd = onets.fill_params(onets.dispnet_layers(), seed=1)
+    psd = onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2)
+    fsd = onets.fill_params(onets.featnet_layers(), seed=3)
+    disp, pose, feat = DispNetS.DispNetS(), PoseExpNet.PoseExpNet(output_exp=True), feat_extractor.FeatExtractor()
+    for m, sd in ((disp, dsd), (pose, psd), (feat, fsd)):
+        m.load_state_dict({k: v.clone() for k, v in sd.items()})
+        m.cuda().train()
+    feat.requires_grad_(False)                                      # train.prototxt:4869-: lr_mult 0
+    batch = synthetic_batch(b, h, w, seed=1234, device="cuda")
+    loss, terms = paper_losses(disp, pose, batch, feat_extractor=feat)
+    loss.backward()
+    cb = osteps.synthetic_batch(b, h, w, seed=1234)
+    cb["T_R2L_se3"] = batch["T_R2L_se3"].cpu()
+    ref, grads = osteps.step_paper(dsd, psd, cb, feat_sd=fsd)
+    for k in ("photo", "smooth", "feat", "total"):
+        assert rel_err(terms[k], ref[k]) < 1e-4, k
+    assert all(p.grad is None for p in feat.parameters())
+    for name, mod in (("disp", disp), ("pose", pose)):
+        for k, p in mod.named_parameters():
+            if k in grads[name]:
+                r = grads[name][k].double()
+                assert float((p.grad.double().cpu() - r).norm()) <= 2e-3 * max(float(r.norm()), 1e-30), (name, k)
