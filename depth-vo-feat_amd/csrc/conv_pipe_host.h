@@ -295,7 +295,8 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     static const int ks_thr = dvf_tune("DVF_PIPE_KSTHR") ? atoi(dvf_tune("DVF_PIPE_KSTHR")) : 160;       // tuning knobs
     static const int ks_tgt = dvf_tune("DVF_PIPE_KSTGT") ? atoi(dvf_tune("DVF_PIPE_KSTGT")) : 256;
     const int KS0 = nblk < ks_thr ? (int)(ks_tgt / nblk) : 1;     // split-K factor before clamping to the chunk count
-    const size_t PIPE_LDS_BUDGET = (nblk * KS0 <= 256 ? 150 : 76) * 1024;
+    static const int big_lds_kb = dvf_tune("DVF_PIPE_BIGLDS_KB") ? atoi(dvf_tune("DVF_PIPE_BIGLDS_KB")) : 150;   // tuning knob
+    const size_t PIPE_LDS_BUDGET = (nblk * KS0 <= 256 ? big_lds_kb : 76) * 1024;
     int CK = TBU >= 5 ? 8 : 16;                          // (the 5- and 7-tap kernels are only built for CK <= 8)
     while (CK > 4 && lds_bytes(CK) > PIPE_LDS_BUDGET) CK >>= 1;
     while (CK > 4 && CK / 2 >= maxc) CK >>= 1;

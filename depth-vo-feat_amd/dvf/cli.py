@@ -56,7 +56,26 @@ def save_best(output_dir, named_modules):
         torch.save({k: v.detach().cpu().clone() for k, v in module.state_dict().items()}, os.path.join(output_dir, fname))
 
 
-def run_training(args, nets, loss_fn, lr, betas, weight_decay, term_names, ckpt_names, n_views=2):
+@torch.no_grad()
+def validate(pose_net, val_loader, device):
+    """Reference train.py:220-247: mean over the validation SAMPLES of the per-batch L1 between the predicted relative
+    pose (network output 0 through the se(3) exponential map, se3_generate.py) and the ground-truth 4x4 transform.
+    The pose network runs in eval mode on (later frame, [earlier frame, earlier frame])."""
+    from se3_generate import generate_se3
+    was_training = pose_net.training
+    pose_net.eval()
+    total = torch.zeros((), device=device)
+    for data, target in val_loader:
+        data, target = data.float().to(device), target.float().to(device)
+        tgt, ref = data[:, :3].contiguous(), data[:, 3:].contiguous()
+        _, pose = pose_net(tgt, [ref, ref])
+        out = generate_se3(pose[:, 0].reshape(-1, 6, 1, 1)).view(-1, 4, 4)
+        total += torch.nn.functional.l1_loss(out, target)                 # (the reference sums the per-batch means, :232)
+    pose_net.train(was_training)
+    return float(total) / max(len(val_loader.dataset), 1)
+
+
+def run_training(args, nets, loss_fn, lr, betas, weight_decay, term_names, ckpt_names, n_views=2, val_fn=None):
     """Epoch loop.  ``loss_fn(batch) -> (loss, terms)``; ``nets``: list of modules in optimizer-group order."""
     rank, world, device = args._rank, args._world, args._device
     params = [p for net in nets for p in net.parameters()]
@@ -126,8 +145,14 @@ def run_training(args, nets, loss_fn, lr, betas, weight_decay, term_names, ckpt_
         if rank == 0:
             msg = " ".join(f"{k}: {v:.9f}" for k, v in zip(term_names, means))
             print(f"Train epoch {epoch}: {msg}  [{args.batch_size * world * args.steps_per_epoch / dt:.1f} samples/s]", flush=True)
-            if means[0] < best:
-                best = means[0]
+            # checkpoint criterion: the reference's validate() (train.py:238-247) when a validation set is given,
+            # else the best training loss
+            score = means[0]
+            if val_fn is not None:
+                score = val_fn()
+                print("Test set: Average loss: {:.6f} [BEST:{}]".format(score, score < best), flush=True)
+            if score < best:
+                best = score
                 save_best(args.output_dir, ckpt_names)
     if world > 1:
         dist.destroy_process_group()

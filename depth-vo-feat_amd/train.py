@@ -3,9 +3,10 @@
 4-scale photometric loss (explainability masks), explainability regulariser, smoothness and the stereo-pose MSE.
 
 Same flags and defaults as the reference (train.py:31-67).  Differences, all forced by scope:
-data is the seeded synthetic stream (the KITTI loaders are out of scope), multi-GPU is one process per GPU with
-RCCL all-reduce instead of nn.DataParallel, ``validate()`` (odometry L1 against ground-truth poses of sequence 00,
-train.py:220-247) needs that dataset and is replaced by best-training-loss checkpointing with the same file names.
+data is the seeded synthetic stream unless --data-root is given, multi-GPU is one process per GPU with RCCL all-reduce
+instead of nn.DataParallel.  ``validate()`` (odometry L1 against the ground-truth relative poses of the test sequences,
+train.py:220-247) runs after every epoch when --val-root points at a KITTI-odometry tree (sequences/<seq>/image_2,
+poses/<seq>.txt) and then decides the best checkpoint like the reference; otherwise the best training loss does.
 
     python train.py -b 4 --epochs 2                       # 1 GPU
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py -b 4
@@ -48,6 +49,7 @@ parser.add_argument("--smooth-loss-factor", type=float, metavar="W", default=2)
 parser.add_argument("-g", "--gpu-id", type=int, metavar="N", default=-1, help="accepted for compatibility; ranks pick LOCAL_RANK")
 parser.add_argument("--output-dir", type=str, default="./checkpoints")
 parser.add_argument("--nb-ref-imgs", type=int, default=2, help="reference views (2 = temporal + stereo; 4 = 5-frame window)")
+parser.add_argument("--val-root", default=None, help="KITTI odometry tree for validate() on --test-sequences (train.py:220-247)")
 cli.add_common_flags(parser)
 
 
@@ -75,9 +77,16 @@ def main():
                                 args.smooth_loss_weight, args.smooth_loss_factor, args.rotation_mode, args.padding_mode)
 
     terms = ["total", "photo", "smooth", "lr"] + (["exp"] if args.mask_loss_weight > 0 else [])
+    val_fn = None
+    if args.val_root and args._rank == 0:
+        from dataset import pose_framework_KITTI
+        val_set = pose_framework_KITTI(args.val_root, args.test_sequences, img_height=args.height, img_width=args.width,
+                                       shuffle=False)
+        val_loader = torch.utils.data.DataLoader(val_set, batch_size=args.batch_size, shuffle=False, num_workers=0)
+        val_fn = lambda: cli.validate(pose_exp_net, val_loader, args._device)      # noqa: E731
     cli.run_training(args, [disp_net, pose_exp_net], loss_fn, args.lr, (args.momentum, args.beta), args.weight_decay,
                      terms, [("best_vo_checkpoint.pth.tar", pose_exp_net), ("best_depth_checkpoint.pth.tar", disp_net)],
-                     n_views=max(2, args.nb_ref_imgs))
+                     n_views=max(2, args.nb_ref_imgs), val_fn=val_fn)
 
 
 if __name__ == "__main__":

@@ -79,3 +79,25 @@ def test_dvo_stereo_pose_convention_reaches_the_kernel():
     # (0.1 read as a rotation about x moves the view by ~6 rows and not at all along x: the ramp then mismatches by the
     # whole 1.86 px shift)
     assert float(bad) > 100 * max(float(loss), 1e-6), (float(bad), float(loss))     # the convention clash is not silent
+
+
+def test_train_with_validate_on_odometry_tree(tmp_path):
+    """train.py on dataset files with the reference's validate() (train.py:220-247) deciding the best checkpoint: pose
+    network in eval mode on consecutive odometry frames, se(3) exponential map on the GPU, L1 against the relative pose."""
+    from test_dataset_odometry import _make_odometry_tree
+    root = _make_tree(tmp_path, n=5)
+    (tmp_path / "odo").mkdir()
+    val_root, _ = _make_odometry_tree(tmp_path / "odo")
+    out = tmp_path / "ckpt"
+    cmd = [sys.executable, os.path.join(PKG, "train.py"), "--data-root", str(root), "--val-root", str(val_root), "--epochs", "2",
+           "-b", "2", "--height", "64", "--width", "128", "--output-dir", str(out), "-m", "0.2", "--test-sequences", "00"]
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + ROOT)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    val = [l for l in res.stdout.splitlines() if l.startswith("Test set: Average loss:")]
+    assert len(val) == 2
+    v0 = float(val[0].split("loss:")[1].split()[0])
+    assert v0 == v0 and 0 < v0 < 10 and "[BEST:True]" in val[0]
+    assert os.path.exists(os.path.join(out, "best_vo_checkpoint.pth.tar"))
+    train = [l for l in res.stdout.splitlines() if l.startswith("Train epoch")]
+    assert len(train) == 2 and "exp:" in train[0]

@@ -17,7 +17,10 @@ for name, segs, cout, k, s, p, op, tr, act, (n, h, w), ohw in ns["LAYERS"]:
     wt = (torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), device="cuda") / (cin * k * k) ** 0.5).requires_grad_(what == "wgrad")
     b = torch.zeros(cout, device="cuda")
     cfg = (k, s, p, op, tr, act, 1.0, 0.0, ohw)
+    flush = torch.empty(160 << 20, device="cuda") if os.environ.get("FLUSH") else None     # 640 MB: beyond L2 + Infinity Cache
     for _ in range(5):
+        if flush is not None:
+            flush.zero_()
         out = ConvFn.apply(wt, b, cfg, *xs)
         if what != "fwd":
             out.backward(torch.ones_like(out))
