@@ -55,6 +55,7 @@ SIGNATURES = {
     "dvf_photo_partials_floats": (c_i64, [c_i] * 4),
     "dvf_photo_pose_ws_floats": (c_i64, [c_i] * 4),
     "dvf_photo_loss_bwd": (c_i, [c_fp, c_pp, c_i] + [c_fp] * 9 + [c_pp, c_fp, c_fp] + [c_i] * 4 + [c_f, c_u32, c_fp]),
+    "dvf_imresize_u8": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_fp]),
     "dvf_edge_smooth_fwd": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_f, c_i, c_fp]),
     "dvf_edge_smooth_partials_floats": (c_i64, [c_i] * 3),
     "dvf_edge_smooth_bwd": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_f, c_fp]),

@@ -48,11 +48,15 @@ def imresize(arr, size):
 
 class dataset(data.Dataset):
     def __init__(self, transform=None, seed=9999, img_height=160, img_width=608, shuffle=True,
-                 root="./data/kitti_eigen", listing=None):
+                 root="./data/kitti_eigen", listing=None, raw=False):
+        """raw=True (this build's extension): __getitem__ returns the three frames as DECODED uint8 [H0,W0,3] tensors
+        instead of resized float ones; ``to_batch_raw`` then performs the reference's imresize on the GPU
+        (dvf.image_ops.gpu_imresize, bit-identical to the host path) -- use ``collate_raw`` in the DataLoader."""
         np.random.seed(seed)
         random.seed(seed)
         self.shuffle = shuffle
         self.transform = transform
+        self.raw = raw
         self.height, self.width = img_height, img_width
         self.root = root
         self.listing = listing if listing is not None else os.path.join(root, "train.txt")
@@ -78,6 +82,13 @@ class dataset(data.Dataset):
 
     def __getitem__(self, index):
         s = self.samples[index]
+        if self.raw:
+            frames = [torch.from_numpy(np.ascontiguousarray(imread(s[k]))) for k in ("right_1", "left_2", "right_2")]
+            intrinsics = np.genfromtxt(s["intrinsics"]).astype(np.float32).reshape((3, 3))
+            f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).type(torch.FloatTensor)
+            return (frames[0], frames[1], frames[2], f32(intrinsics), f32(np.linalg.inv(intrinsics)),
+                    f32(np.load(s["raw_K"], allow_pickle=False).astype(np.float32)),
+                    f32(np.load(s["T_R2L"], allow_pickle=False).astype(np.float32)))
         imgs = [imread(s[k]).astype(np.float32) for k in ("right_1", "left_2", "right_2")]
         imgs = [imresize(im, (self.height, self.width)).astype(np.float32) for im in imgs]
         intrinsics = np.genfromtxt(s["intrinsics"]).astype(np.float32).reshape((3, 3))
@@ -124,3 +135,17 @@ def to_batch(sample_batch, device):
     se3 = T.reshape(T.shape[0], -1)[:, :6].contiguous()
     return {"img_R1": r1.contiguous(), "img_L2": l2.contiguous(), "img_R2": r2.contiguous(), "K": K.contiguous(),
             "Kinv": Kinv.contiguous(), "raw_K": raw_K, "T_R2L_se3": se3, "T_R2L": se3_to_tr_euler(se3).contiguous()}
+
+
+def collate_raw(samples):
+    """DataLoader collate_fn for ``dataset(raw=True)``: frames stay a list (native sizes may differ between drives),
+    the small tensors are stacked."""
+    cols = list(zip(*samples))
+    return [list(cols[0]), list(cols[1]), list(cols[2])] + [torch.stack(c) for c in cols[3:]]
+
+
+def to_batch_raw(raw_batch, device, size):
+    """``collate_raw`` output -> the batch dict, with the reference's per-frame imresize done on the GPU."""
+    from dvf.image_ops import gpu_imresize
+    frames = [torch.stack([gpu_imresize(f.to(device, non_blocking=True), size) for f in col]) for col in raw_batch[:3]]
+    return to_batch(frames + list(raw_batch[3:]), device)

@@ -129,6 +129,17 @@ int dvf_photo_loss_bwd(const float *tgt, const float *const *srcs, int V, const 
                        float in_scale, uint32_t flags, void *stream);
 int64_t dvf_photo_pose_ws_floats(int B, int H, int W, int V);
 
+/* ---------------------------------------------------------------- input pipeline: frame -> network input on the GPU
+ * Replaces, per frame, `imresize(imread(f).astype(np.float32), (H, W))` of the reference's loaders (un_dataset.py:63-66,
+ * dataset.py:50-51; scipy.misc.imresize = bytescale [min,max]->[0,255] + PIL BILINEAR on uint8), bit for bit:
+ *   src_hwc uint8 [IH,IW,C] (the decoded frame) -> dst_chw float32 [C,OH,OW] (integer values 0..255).
+ * hbounds/hcoef [OW,2]/[OW,hksize] and vbounds/vcoef [OH,2]/[OH,vksize]: DEVICE int32 tables of PIL's separable triangle
+ * filter in 22-bit fixed point (dvf/image_ops.py builds them as Pillow's precompute_coeffs / normalize_coeffs_8bpc do);
+ * tmp: uint8 [IH,OW,C] workspace; minmax: 2 int32 workspace. */
+int dvf_imresize_u8(const uint8_t *src_hwc, int IH, int IW, int C, const int *hbounds, const int *hcoef, int hksize,
+                    const int *vbounds, const int *vcoef, int vksize, uint8_t *tmp, int *minmax, float *dst_chw, int OH, int OW,
+                    void *stream);
+
 /* ---------------------------------------------------------------- edge-aware smoothness (paper / Caffe graph variant)
  * experiments/depth_odometry_feature/train.prototxt:4452-4661 with caffe/include/caffe/filler.hpp:267-316 and
  * abs_loss_layer.cu:10-34: loss_out[0] (+)= weight * (sum |exp(-k sum_c |d_y I_c|) d_y D| + sum |exp(-k sum_c |d_x I_c|) d_x D|) / B

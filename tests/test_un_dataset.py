@@ -86,3 +86,36 @@ def test_se3_to_tr_euler_is_the_same_rigid_motion():
     from dvf.synthetic import synthetic_batch
     b = synthetic_batch(2, 8, 16)
     assert torch.allclose(un_dataset.se3_to_tr_euler(b["T_R2L_se3"]), b["T_R2L"], atol=1e-7)
+
+
+def test_pil_resample_tables_reproduce_pil():
+    """The fixed-point coefficient tables of dvf.image_ops (Pillow's precompute_coeffs / normalize_coeffs_8bpc) drive an
+    integer emulation of the two resampling passes that must equal PIL's own BILINEAR resize exactly -- down- and
+    up-scaling.  (The GPU kernels run the same arithmetic: tests/test_gpu_image_ops.py.)"""
+    from dvf.image_ops import _coeffs
+    rng = np.random.default_rng(0)
+    for (ih, iw), (oh, ow) in (((94, 311), (64, 208)), ((37, 123), (64, 128))):
+        img = rng.integers(3, 250, size=(ih, iw, 3), dtype=np.uint8)
+        ref = un_dataset.imresize(img.astype(np.float32), (oh, ow)).astype(np.int64)
+        bs = un_dataset.bytescale(img.astype(np.float32)).astype(np.int64)
+        hb, hk, _ = _coeffs(iw, ow)
+        vb, vk, _ = _coeffs(ih, oh)
+        tmp = np.zeros((ih, ow, 3), dtype=np.int64)
+        for ox in range(ow):
+            x0, n = hb[ox]
+            tmp[:, ox, :] = np.clip(((1 << 21) + np.tensordot(bs[:, x0:x0 + n, :], hk[ox, :n].astype(np.int64), axes=([1], [0]))) >> 22, 0, 255)
+        out = np.zeros((oh, ow, 3), dtype=np.int64)
+        for oy in range(oh):
+            y0, n = vb[oy]
+            out[oy] = np.clip(((1 << 21) + np.tensordot(tmp[y0:y0 + n], vk[oy, :n].astype(np.int64), axes=([0], [0]))) >> 22, 0, 255)
+        assert np.array_equal(out, ref)
+
+
+def test_raw_mode_and_collate(tmp_path):
+    root = _make_tree(tmp_path)
+    ds = un_dataset.dataset(img_height=16, img_width=48, root=str(root), raw=True)
+    r1, l2, r2, K, Kinv, raw_K, T = ds[0]
+    assert r1.dtype == torch.uint8 and tuple(r1.shape) == (37, 123, 3) and tuple(K.shape) == (3, 3)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=0, collate_fn=un_dataset.collate_raw)
+    b = next(iter(loader))
+    assert isinstance(b[0], list) and len(b[0]) == 2 and tuple(b[3].shape) == (2, 3, 3) and tuple(b[6].shape) == (2, 1, 6)
