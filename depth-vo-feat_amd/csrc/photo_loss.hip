@@ -274,23 +274,43 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(PhotoArgs a) {
     }
 }
 
-// Deterministic second stage: one block sums the per-block partials in a fixed order.
-__global__ __launch_bounds__(256) void photo_reduce_kernel(const float *partials, int64_t nblk, int V, float inv_n,
-                                                           float *loss_out, float *view_loss) {
-    __shared__ float red[4];
-    float total = 0.f;
-    for (int v = 0; v < V; ++v) {
-        float s = 0.f;
-        for (int64_t i = threadIdx.x; i < nblk; i += 256) s += partials[i * V + v];
-        s = wave_sum(s);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-        __syncthreads();
-        const float t = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;     // mean over B*C*H*W
-        __syncthreads();
-        if (threadIdx.x == 0 && view_loss) view_loss[v] = t;
-        total += t;
+// Deterministic second stage: one block of 1024 threads sums the per-block partials in a fixed order (thread t takes
+// blocks t, t + 1024, ... with four loads in flight; then a wave reduction and a fixed-order sum of the 16 wave totals).
+__global__ __launch_bounds__(1024) void photo_reduce_kernel(const float *partials, int64_t nblk, int V, float inv_n,
+                                                            float *loss_out, float *view_loss) {
+    __shared__ float red[16][DVF_MAX_VIEWS];
+    float s[DVF_MAX_VIEWS] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i0 = threadIdx.x; i0 < nblk; i0 += 4096) {
+        float v[4][DVF_MAX_VIEWS];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < DVF_MAX_VIEWS; ++k) {
+                const int64_t i = i0 + 1024 * u;
+                v[u][k] = (i < nblk && k < V) ? partials[i * V + k] : 0.f;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < DVF_MAX_VIEWS; ++k) s[k] += v[u][k];
     }
-    if (threadIdx.x == 0) loss_out[0] = total;
+#pragma unroll
+    for (int k = 0; k < DVF_MAX_VIEWS; ++k) {
+        const float w = wave_sum(s[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int k = 0; k < V; ++k) {
+            float t = 0.f;
+            for (int w = 0; w < 16; ++w) t += red[w][k];
+            t *= inv_n;                                      // mean over B*C*H*W (or / B: DVF_CAFFE_ABSLOSS)
+            if (view_loss) view_loss[k] = t;
+            total += t;
+        }
+        loss_out[0] = total;
+    }
 }
 
 // L1 sign of channel c of a view, two bits per channel in (lo: c < 16, hi: c >= 16): 0 -> 0, 1 -> +1, 2 -> -1.
@@ -517,22 +537,29 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(PhotoArgs a) {
     }
 }
 
-// Second stage of the pose-gradient reduction: pose_ws[(v*B+b)*12 + k] = sum over the blocks of image b, fixed order.
-__global__ __launch_bounds__(256) void pose_sum_kernel(const float *part, float *pose_ws, int V, int B, int blocks_per_img) {
-    __shared__ float red[21][12];
+// Second stage of the pose-gradient reduction: pose_ws[(v*B+b)*12 + k] = sum over the blocks of image b, fixed order
+// (1008 threads = 84 strided partial sums per value, then a fixed-order sum of the 84).
+__global__ __launch_bounds__(1024) void pose_sum_kernel(const float *part, float *pose_ws, int V, int B, int blocks_per_img) {
+    __shared__ float red[84][12];
     const int v = blockIdx.x / B, b = blockIdx.x - v * B;
     const int t = threadIdx.x;
-    if (t < 252) {
+    if (t < 1008) {
         const int k = t % 12, j = t / 12;
         const float *p = part + ((int64_t)b * blocks_per_img * V + v) * 12 + k;
-        float s = 0.f;
-        for (int i = j; i < blocks_per_img; i += 21) s += p[(int64_t)i * V * 12];
-        red[j][k] = s;
+        float s0 = 0.f, s1 = 0.f;
+        int i = j;
+        for (; i + 84 < blocks_per_img; i += 168) {          // two loads in flight
+            const float a0 = p[(int64_t)i * V * 12], a1 = p[(int64_t)(i + 84) * V * 12];
+            s0 += a0;
+            s1 += a1;
+        }
+        if (i < blocks_per_img) s0 += p[(int64_t)i * V * 12];
+        red[j][k] = s0 + s1;
     }
     __syncthreads();
     if (t < 12) {
         float s = 0.f;
-        for (int j = 0; j < 21; ++j) s += red[j][t];
+        for (int j = 0; j < 84; ++j) s += red[j][t];
         pose_ws[((int64_t)v * B + b) * 12 + t] = s;
     }
 }
@@ -603,7 +630,7 @@ int dvf_photo_loss_fwd(const float *tgt, const float *const *srcs, int V, const 
     });
     if (rc != DVF_OK) return rc;
     const float inv_n = (flags & DVF_CAFFE_ABSLOSS) ? 1.f / (float)B : 1.f / ((float)B * (float)C * (float)H * (float)W);
-    photo_reduce_kernel<<<1, 256, 0, st>>>(partials, (int64_t)grid.x * grid.y * grid.z, V, inv_n, loss_out, view_loss);
+    photo_reduce_kernel<<<1, 1024, 0, st>>>(partials, (int64_t)grid.x * grid.y * grid.z, V, inv_n, loss_out, view_loss);
     DVF_LAUNCH_CHECK();
     return DVF_OK;
 }
@@ -644,7 +671,7 @@ int dvf_photo_loss_bwd(const float *tgt, const float *const *srcs, int V, const 
     if (rc != DVF_OK) return rc;
     (void)nblk;
     if (g_pose) {
-        pose_sum_kernel<<<V * B, 256, 0, st>>>(a.pose_part, pose_ws, V, B, (int)(grid.x * grid.y));
+        pose_sum_kernel<<<V * B, 1024, 0, st>>>(a.pose_part, pose_ws, V, B, (int)(grid.x * grid.y));
         DVF_LAUNCH_CHECK();
         pose_finalize_kernel<<<(V * B + 63) / 64, 64, 0, st>>>(pose, pose_ws, g_pose, V * B, rot_mode(flags));
         DVF_LAUNCH_CHECK();
