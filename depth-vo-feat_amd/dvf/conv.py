@@ -46,14 +46,21 @@ def _workspace(nfloats, device):
 
 
 _PACK_REGISTRY = []    # [weakref(weight), desc, segc, kind, cache entry] of every packed copy in use
-_PACK_TABLE = {"n": -1}
+_PACK_TABLES = {}      # (id(owner), bucket) -> job tables of the layers of one optimizer bucket (None: all layers)
 _PACK_SMALL_LDS = 20 * 1024    # bytes: eight 256-thread pack blocks of this size share a CU
 
 
-def repack_all():
-    """Refresh every packed weight copy with one launch per tile-size group (called by FlatAdam.step() right after the
-    update, so the convolutions of the next step find their copies current).  The job tables are built once per set of
-    layers."""
+def _stamp(w):
+    """What a packed copy was made from: storage, torch's version counter, the owning optimizer's update count of this
+    parameter (FlatAdam updates through raw pointers) and the manual invalidation epoch."""
+    return (w.data_ptr(), w._version, getattr(w, "_dvf_epoch", 0), L.PACK_EPOCH)
+
+
+def repack_all(owner=None, bucket=None):
+    """Refresh packed weight copies with one launch per tile-size group (called by FlatAdam right after an update, so
+    the convolutions of the next step find their copies current).  owner/bucket: only the layers whose weight lives in
+    that bucket of that optimizer (torch.optim users call ``repack_all()`` for everything, or rely on the lazy
+    per-layer refresh driven by the weight's version counter).  The job tables are built once per set of layers."""
     if not _PACK_REGISTRY:
         return
     lib = L.lib()
@@ -61,7 +68,11 @@ def repack_all():
     live = [(r, w) for r, w in live if w is not None]
     if len(live) != len(_PACK_REGISTRY) and not torch.cuda.is_current_stream_capturing():
         _PACK_REGISTRY[:] = [r for r, _ in live]          # drop the layers of models that no longer exist
-    t = _PACK_TABLE
+    if owner is not None:
+        live = [(r, w) for r, w in live if getattr(w, "_dvf_owner", None) is owner and w._dvf_bucket == bucket]
+    if not live:
+        return
+    t = _PACK_TABLES.setdefault((id(owner) if owner is not None else 0, bucket), {"n": -1})
     key = tuple((id(r), w.data_ptr()) for r, w in live)
     if t.get("key") != key:
         if torch.cuda.is_current_stream_capturing():
@@ -72,7 +83,7 @@ def repack_all():
                 _, desc, segc, kind, ent = r
                 L.check(lib.dvf_conv2d_pack(ctypes.byref(desc), L.int_array(segc), len(segc), kind, L.dev(w), L.dev(ent[0]),
                                             L.stream()), "dvf_conv2d_pack")
-                ent[1] = (w.data_ptr(), w._version, L.PACK_EPOCH)
+                ent[1] = _stamp(w)
             return
         # jobs are grouped by the LDS tile they need: a launch reserves the maximum of its jobs for every block, and
         # the few large-kernel layers (7x7, 5x5: ~50 KB) would otherwise hold the 3x3 bulk to three blocks per CU
@@ -110,7 +121,7 @@ def repack_all():
         L.check(lib.dvf_conv2d_pack_batch(q["jobs"].data_ptr(), q["prefix"].data_ptr(), q["block_job"].data_ptr(), q["njobs"],
                                           q["total"], q["lds"], L.stream()), "dvf_conv2d_pack_batch")
     for r, w in live:
-        r[4][1] = (w.data_ptr(), w._version, L.PACK_EPOCH)
+        r[4][1] = _stamp(w)
 
 
 def _packed_weights(weight, holder, desc, segc, kind):
@@ -135,7 +146,7 @@ def _packed_weights(weight, holder, desc, segc, kind):
     buf = ent[0]
     if buf is None:
         return None, (_workspace(ent[2], weight.device) if ent[2] else None)
-    stamp = (weight.data_ptr(), weight._version, L.PACK_EPOCH)
+    stamp = _stamp(holder)
     if ent[1] != stamp:
         with L.timed("conv_pack", 0.0, 8.0 * weight.numel()):
             L.check(lib.dvf_conv2d_pack(ctypes.byref(desc), L.int_array(segc), len(segc), kind, L.dev(weight, "weight"),

@@ -22,11 +22,16 @@ class FlatAdam:
     """torch.optim.Adam over flat arenas.  ``params``: iterable of nn.Parameter (all nets together)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world_size=1,
-                 bucket_mb=25.0, process_group=None, overlap=True, always_reduce=False, wgrad_stream=True):
+                 bucket_mb=25.0, process_group=None, overlap=True, always_reduce=False, wgrad_stream=True, early_update=True):
         """overlap=True: buckets are all-reduced on a side stream from inside backward (eager execution).
         overlap=False: backward only marks gradients; ``step()`` all-reduces the buckets on the current stream --
         the mode used when forward+backward are replayed from a HIP graph.  always_reduce: run the exchange even
         with world_size 1 (single-GPU rehearsal of the multi-GPU code path).
+        early_update (with overlap): a bucket whose gradients are complete is UPDATED from inside backward on the
+        communication / update stream -- (all-reduce,) Adam on the bucket's slice of the arenas, refresh of the packed
+        weight copies of its layers -- while the rest of backward runs; ``step()`` only finishes what is left.  The
+        deep layers hold most parameters and finish first, so nearly all of the optimizer's HBM streaming hides behind
+        the (matrix-bound) backward of the shallow layers.
         wgrad_stream: weight-gradient kernels run on a second HIP stream.  Nothing in backward consumes a weight
         gradient, so they are off the critical path (dgrad chain) and fill the CUs that a single convolution kernel
         leaves idle; the streams join in ``join_wgrad()`` (called by ``step()``)."""
@@ -55,6 +60,7 @@ class FlatAdam:
             p.data = view
             p.grad = None
             p._dvf_grad = self.flat_g[o:o + n].view_as(p)     # wgrad kernels add straight into this
+            p._dvf_offset = o
             p._dvf_touched = False
             p._dvf_owner = self
         # gradient buckets = contiguous arena slices of ~bucket_mb, in backward order
@@ -67,9 +73,13 @@ class FlatAdam:
                 self.buckets.append({"start": cur_start, "end": end, "params": cur_params, "pending": 0})
                 cur_start, cur_params = end, []
         for bi, b in enumerate(self.buckets):
+            b["index"] = bi
             for p in b["params"]:
                 p._dvf_bucket = bi
-        self._comm_stream = torch.cuda.Stream(device=dev) if (self.exchange and self.overlap and dev.type == "cuda") else None
+        self.early_update = bool(early_update) and self.overlap and dev.type == "cuda"
+        self._comm_stream = torch.cuda.Stream(device=dev) if ((self.exchange or self.early_update) and self.overlap and
+                                                               dev.type == "cuda") else None
+        self._adam_started = False   # the step counter has been advanced for the current step
         self._main_stream = None     # compute stream of the step (recorded by zero_grad)
         self.n_reduced = 0           # buckets exchanged so far (tests / bench bookkeeping)
         self._ranges = None
@@ -108,6 +118,8 @@ class FlatAdam:
         for b in self.buckets:
             b["pending"] = sum(1 for p in b["params"] if p._dvf_touched or self._ranges is None)
             b["launched"] = False
+            b["updated"] = False
+        self._adam_started = False
 
     def grad_ready(self, p):
         """A weight/bias gradient has been enqueued on the compute stream."""
@@ -115,23 +127,57 @@ class FlatAdam:
             p._dvf_touched = True
             p.grad = p._dvf_grad            # expose it the torch way
             self._ranges = None
-        if not (self.exchange and self.overlap):
+        if not ((self.exchange or self.early_update) and self.overlap):
             return
         b = self.buckets[p._dvf_bucket]
         b["pending"] -= 1
         if b["pending"] <= 0 and not b["launched"] and self._ranges is not None:
             self._launch_bucket(b)
 
+    def _bucket_ranges(self, b):
+        """Contiguous arena ranges of the bucket's parameters that received a gradient."""
+        rngs = []
+        for p in b["params"]:
+            if not p._dvf_touched:
+                continue
+            o = p._dvf_offset
+            end = o + (p.numel() + 63) // 64 * 64
+            if rngs and rngs[-1][1] == o:
+                rngs[-1][1] = end
+            else:
+                rngs.append([o, end])
+        return rngs
+
+    def _adam_bucket(self, b):
+        """Fused Adam on the bucket's slice of the arenas + refresh of the packed weight copies of its layers, on the
+        current stream."""
+        lib = L.lib()
+        for o, e in self._bucket_ranges(b):
+            L.check(lib.dvf_adam_step(L.dev(self.flat_p[o:e]), L.dev(self.flat_g[o:e]), L.dev(self.flat_m[o:e]),
+                                      L.dev(self.flat_v[o:e]), e - o, L.dev(self.opt_state), 0 if self._adam_started else 1,
+                                      self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                      1.0 / self.world_size, L.stream()), "dvf_adam_step")
+            self._adam_started = True
+        for p in b["params"]:            # packed convolution weights (dvf/conv.py) of the updated layers are stale now
+            if p._dvf_touched:
+                p._dvf_epoch = getattr(p, "_dvf_epoch", 0) + 1
+        from . import conv as _conv
+        _conv.repack_all(owner=self, bucket=b["index"])
+        b["updated"] = True
+
     def _launch_bucket(self, b):
         b["launched"] = True
         grads = self.flat_g[b["start"]:b["end"]]
-        if self._comm_stream is None:                       # CPU tensors (gloo) or overlap=False: current stream
-            dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
-            self.n_reduced += 1
+        if self._comm_stream is None or L.SERIALIZE:        # CPU tensors (gloo), overlap=False or serialised: current stream
+            if self.exchange:
+                dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
+                self.n_reduced += 1
             return
         # The bucket's gradients were written by kernels on EVERY compute stream of the step: bias gradients and thin
         # layers on the stream the layer's backward ran on (the main stream for the depth network, the auxiliary stream
-        # for the pose network), weight gradients on the side stream behind each of the two.  The exchange waits for all.
+        # for the pose network), weight gradients on the side stream behind each of the two.  The exchange / update
+        # waits for all of them (and, for the update, for the dgrad kernels that still read the bucket's weights: they
+        # were enqueued on those same streams before this point).
         comm = self._comm_stream
         comm.wait_stream(torch.cuda.current_stream())         # the stream this grad_ready() was called on
         if self._main_stream is not None:
@@ -142,8 +188,11 @@ class FlatAdam:
             if dev == comm.device:
                 comm.wait_stream(aux)
         with torch.cuda.stream(comm):
-            dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
-        self.n_reduced += 1
+            if self.exchange:
+                dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
+                self.n_reduced += 1
+            if self.early_update and self._ranges is not None:
+                self._adam_bucket(b)
 
     # ------------------------------------------------------------------ optimizer API
     def zero_grad(self):
@@ -169,14 +218,13 @@ class FlatAdam:
         return self._ranges
 
     def synchronize_grads(self):
-        """Finish the data-parallel exchange: launch what backward could not (first step, stragglers) and make the
-        compute stream wait for the side stream."""
-        if not self.exchange:
-            return
+        """Finish the data-parallel exchange (and the early updates): launch what backward could not (first step,
+        stragglers) and make the compute stream wait for the communication / update stream."""
         self._touched_ranges()
-        for b in self.buckets:
-            if not b["launched"] and any(p._dvf_touched for p in b["params"]):
-                self._launch_bucket(b)
+        if self.exchange:
+            for b in self.buckets:
+                if not b["launched"] and any(p._dvf_touched for p in b["params"]):
+                    self._launch_bucket(b)
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
 
@@ -184,17 +232,9 @@ class FlatAdam:
         L.join_aux_streams()         # backward kernels of a sub-network that ran on the auxiliary stream
         self.join_wgrad()
         self.synchronize_grads()
-        lib = L.lib()
-        first = True
-        for o, e in self._touched_ranges():
-            L.check(lib.dvf_adam_step(L.dev(self.flat_p[o:e]), L.dev(self.flat_g[o:e]), L.dev(self.flat_m[o:e]),
-                                      L.dev(self.flat_v[o:e]), e - o, L.dev(self.opt_state), 1 if first else 0,
-                                      self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                      1.0 / self.world_size, L.stream()), "dvf_adam_step")
-            first = False
-        L.PACK_EPOCH += 1            # packed convolution weights (dvf/conv.py) are stale now:
-        from . import conv as _conv  # refresh them all with one launch
-        _conv.repack_all()
+        for b in self.buckets:       # buckets that were not updated from inside backward
+            if not b["updated"] and any(p._dvf_touched for p in b["params"]):
+                self._adam_bucket(b)
 
     def set_lr(self, lr):
         self.lr = float(lr)

@@ -232,7 +232,7 @@ def join_aux_streams():
             cur.wait_stream(s)
 
 
-PACK_EPOCH = 0  # bumped by FlatAdam.step(): packed copies of the convolution weights are stale after it
+PACK_EPOCH = 0  # manual invalidation of every packed weight copy (FlatAdam bumps a per-parameter epoch instead: dvf/conv.py::_stamp)
 
 
 def timed(kind, flops=0.0, nbytes=0.0, tag=""):
