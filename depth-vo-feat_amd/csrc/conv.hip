@@ -21,6 +21,7 @@
 #include <string.h>
 #include "conv_pipe.h"
 #include "conv_head.h"
+#include "wgrad_pipe.h"
 
 namespace {
 
@@ -1037,6 +1038,64 @@ int dgrad_segment_unpacked(const dvf_conv_desc *d, const float *dpre, const floa
     for (int t = 0; t < a.KK; ++t) cls[0].tapmap[t] = t;
     return run_classes(a, cls, 1, true, st, ws, ws_floats, ws_need);
 }
+// Plan + launch of the pipelined weight-gradient kernel (wgrad_pipe.hip) for one segment; DVF_ERR_UNSUPPORTED when the
+// geometry is outside its envelope (the register-staged conv_wgrad_kernel then takes the segment).
+static int roundup(int v, int q) { return (v + q - 1) / q * q; }
+int wgrad_pipe_segment(const WgradArgs &o, hipStream_t st) {
+    static const bool off = dvf_tune("DVF_WG_PIPE") && atoi(dvf_tune("DVF_WG_PIPE")) == 0;     // tuning knob
+    if (off) return DVF_ERR_UNSUPPORTED;
+    const int T = o.KH * o.KW;
+    if ((o.S != 1 && o.S != 2) || T > 128 || o.pad < 0 || o.pad > 4) return DVF_ERR_UNSUPPORTED;
+    if ((int64_t)o.N * o.PCtot * o.GH * o.GW * 4 >= ((int64_t)1 << 31) - 16 ||
+        (int64_t)o.N * o.QCtot * o.QH * o.QW * 4 >= ((int64_t)1 << 31) - 16)
+        return DVF_ERR_UNSUPPORTED;                 // 32-bit byte offsets inside the kernel
+    WgpArgs w{};
+    w.P = o.P; w.Q = o.Q; w.G = o.G;
+    w.PCtot = o.PCtot; w.m_base = o.m_base; w.M = o.M; w.QCtot = o.QCtot; w.q_base = o.q_base; w.Cq = o.Cq;
+    w.g_mstride = o.g_mstride; w.g_mbase = o.g_mbase; w.g_cbase = o.g_cbase; w.KK = o.KK; w.KH = o.KH; w.KW = o.KW;
+    w.N = o.N; w.GH = o.GH; w.GW = o.GW; w.QH = o.QH; w.QW = o.QW; w.S = o.S; w.pad = o.pad;
+    const int MT = o.M > 32 ? 2 : 1, MB = 32 * MT, PF = (MB / 2) * WGP_PAIR;
+    w.XA = (o.pad + 3) & ~3;
+    w.RSq = roundup(w.XA + (WGP_BW - 1) * o.S + o.KW - o.pad, 4);
+    w.PHq = (WGP_BH - 1) * o.S + o.KH;
+    w.x4 = (o.GW % 4 == 0 && o.QW % 4 == 0 && ((reinterpret_cast<uintptr_t>(o.P) | reinterpret_cast<uintptr_t>(o.Q)) & 15) == 0) ? 1 : 0;
+    const int piece = w.x4 ? 256 : 64;
+    w.NPIq = cdiv(w.PHq * w.RSq, piece);
+    if (w.NPIq > WGP_MAXQ) return DVF_ERR_UNSUPPORTED;
+    w.PSq = w.NPIq * piece + 4;
+    // columns per block: 128 * NTW >= CK * T.  Cost ~ MFMA time = channel chunks x column tiles per chunk; balanced chunks.
+    int best_cost = 1 << 30, NTW = 0, CK = 0;
+    for (int ntw = 2; ntw >= 1; --ntw) {
+        int ckmax = (128 * ntw) / T;
+        if (ckmax > o.Cq) ckmax = o.Cq;
+        while (ckmax >= 1 && (size_t)2 * (PF + (size_t)ckmax * w.PSq) * 4 > WGP_LDS_CAP) --ckmax;
+        if (ckmax < 1) continue;
+        const int nch = cdiv(o.Cq, ckmax), cost = nch * ntw;
+        if (cost < best_cost) { best_cost = cost; NTW = ntw; CK = cdiv(o.Cq, nch); }
+    }
+    if (!NTW) return DVF_ERR_UNSUPPORTED;
+    w.CK = CK;
+    w.mtiles = cdiv(o.M, MB);
+    w.cchunks = cdiv(o.Cq, CK);
+    w.tilesX = cdiv(o.GW, WGP_BW);
+    w.tilesY = cdiv(o.GH, WGP_BH);
+    w.ntiles = o.N * w.tilesX * w.tilesY;
+    const int64_t W = (int64_t)w.mtiles * w.cchunks * w.ntiles;
+    if (W >= ((int64_t)1 << 30)) return DVF_ERR_UNSUPPORTED;
+    w.W = (int)W;
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    const int nblocks = w.W < ncu ? w.W : ncu;
+    const size_t lds = (size_t)2 * (PF + (size_t)CK * w.PSq) * 4;
+    if (const char *e = dvf_tune("DVF_WG_DBG")) w.dbg = atoi(e);
+    const int rc = dvf_wgrad_pipe_launch(w, MT, NTW, nblocks, lds, st);
+    if (rc == DVF_OK) dvf_plan_note(DVF_K_WGRAD_PIPE, MT, NTW, w.x4, CK, o.S, w.NPIq, nblocks, (int)lds, T, w.RSq, w.PHq);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1100,6 +1159,11 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
             a.P = in_segs[s]; a.PCtot = segc; a.m_base = 0; a.M = segc; a.GH = d->H_in; a.GW = d->W_in;
             a.Q = dpre; a.QCtot = d->C_out; a.q_base = 0; a.Cq = d->C_out; a.QH = d->H_out; a.QW = d->W_out;
             a.g_mstride = (int64_t)d->C_out * KK; a.g_mbase = off; a.g_cbase = 0;
+        }
+        {
+            const int prc = wgrad_pipe_segment(a, st);
+            if (prc == DVF_OK) { off += segc; continue; }
+            if (prc != DVF_ERR_UNSUPPORTED) return prc;
         }
         const int MT = a.M > 32 ? 2 : 1;
         // column tiles per wave: two when the kernel is large, or when that lets fewer channel chunks (each of which

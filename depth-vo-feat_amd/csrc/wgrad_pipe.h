@@ -1,0 +1,31 @@
+// Pipelined weight-gradient kernel (wgrad_pipe.hip), shared with the planner in conv.hip.
+//
+//   G[m][c][ta][tb] += sum over (n, y, x) of  P[n][m][y][x] * Q[n][c][y*S + ta - pad][x*S + tb - pad]
+//
+// Conv2d: P = dL/dpre, Q = layer input;  ConvTranspose2d: P = layer input, Q = dL/dpre (conv.hip fills the roles).
+#pragma once
+#include "dvf_common.h"
+
+struct WgpArgs {
+    const float *P;      // [N, PCtot, GH, GW]; channels m_base .. m_base+M-1 are used
+    const float *Q;      // [N, QCtot, QH, QW]; channels q_base .. q_base+Cq-1 are used
+    float *G;            // G[(g_mbase + m) * g_mstride + (g_cbase + c) * KK + tap]
+    int PCtot, m_base, M, QCtot, q_base, Cq;
+    int64_t g_mstride;
+    int g_mbase, g_cbase, KK, KH, KW;
+    int N, GH, GW, QH, QW, S, pad;
+    int CK;              // Q channels per column chunk (CK * KK <= 128 * NTW columns)
+    int tilesX, tilesY, ntiles, mtiles, cchunks;
+    int PHq, RSq, PSq, NPIq, XA;   // Q patch: rows, row stride, channel stride (floats), DMA pieces per channel, aligned left margin
+    int x4;              // 1: 16-byte DMA lanes (GW % 4 == 0, QW % 4 == 0, 16-byte aligned bases), 0: 4-byte lanes
+    int W;               // work items = mtiles * cchunks * ntiles, split evenly over the blocks of the launch
+    int dbg;             // ablation switches (-DDVF_TUNING builds): 1 no DMA loads, 4 no MFMA, 8 no atomic epilogue
+};
+
+constexpr int WGP_BH = 4, WGP_BW = 32;     // pixel tile of one pipeline step: 4 rows x 32 columns of the P grid
+constexpr int WGP_PAIR = 260;              // LDS floats per pair of P channels (2 x 128 pixels + 4: bank skew)
+constexpr int WGP_MAXQ = 16;               // DMA pieces per Q patch channel
+constexpr size_t WGP_LDS_CAP = 160 * 1024;
+
+// (MT, NTW) in {1,2}^2; S in {1,2}.  Returns DVF_OK / DVF_ERR_*.
+int dvf_wgrad_pipe_launch(const WgpArgs &a, int MT, int NTW, int nblocks, size_t lds_bytes, hipStream_t st);

@@ -170,5 +170,5 @@ def test_bench_plans_are_the_tested_plans():
     missing = sorted(step - layer)
     assert not missing, missing
     kernels = {p[1] for p in step}
-    assert {1, 6} <= kernels, kernels                      # conv_pipe and conv_wgrad at least
+    assert {1, 8} <= kernels, kernels                      # conv_pipe and wgrad_pipe at least
     print("%d distinct plans in the step, all parity-tested; kernels used: %s" % (len(step), sorted(kernels)))
