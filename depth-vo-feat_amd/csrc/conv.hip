@@ -1041,24 +1041,35 @@ int dgrad_segment_unpacked(const dvf_conv_desc *d, const float *dpre, const floa
 // Plan + launch of the pipelined weight-gradient kernel (wgrad_pipe.hip) for one segment; DVF_ERR_UNSUPPORTED when the
 // geometry is outside its envelope (the register-staged conv_wgrad_kernel then takes the segment).
 static int roundup(int v, int q) { return (v + q - 1) / q * q; }
-int wgrad_pipe_segment(const WgradArgs &o, hipStream_t st) {
+int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qsegc, int nseg, hipStream_t st) {
     static const bool off = dvf_tune("DVF_WG_PIPE") && atoi(dvf_tune("DVF_WG_PIPE")) == 0;     // tuning knob
     if (off) return DVF_ERR_UNSUPPORTED;
     const int T = o.KH * o.KW;
     if ((o.S != 1 && o.S != 2) || T > 128 || o.pad < 0 || o.pad > 4) return DVF_ERR_UNSUPPORTED;
     if ((int64_t)o.N * o.PCtot * o.GH * o.GW * 4 >= ((int64_t)1 << 31) - 16 ||
-        (int64_t)o.N * o.QCtot * o.QH * o.QW * 4 >= ((int64_t)1 << 31) - 16)
+        nseg < 1 || nseg > DVF_MAX_SEGS)
         return DVF_ERR_UNSUPPORTED;                 // 32-bit byte offsets inside the kernel
     WgpArgs w{};
-    w.P = o.P; w.Q = o.Q; w.G = o.G;
-    w.PCtot = o.PCtot; w.m_base = o.m_base; w.M = o.M; w.QCtot = o.QCtot; w.q_base = o.q_base; w.Cq = o.Cq;
+    w.P = o.P; w.G = o.G;
+    uintptr_t align = reinterpret_cast<uintptr_t>(o.P);
+    int ctot = 0;
+    for (int s = 0; s < nseg; ++s) {
+        if (!qsegs[s] || qsegc[s] < 1) return DVF_ERR_INVALID_ARG;
+        if ((int64_t)o.N * qsegc[s] * o.QH * o.QW * 4 >= ((int64_t)1 << 31) - 16) return DVF_ERR_UNSUPPORTED;
+        w.Q[s] = qsegs[s]; w.segC[s] = qsegc[s];
+        ctot += qsegc[s];
+        align |= reinterpret_cast<uintptr_t>(qsegs[s]);
+    }
+    if (ctot != o.Cq) return DVF_ERR_INVALID_ARG;
+    w.nseg = nseg;
+    w.PCtot = o.PCtot; w.m_base = o.m_base; w.M = o.M; w.Cq = o.Cq;
     w.g_mstride = o.g_mstride; w.g_mbase = o.g_mbase; w.g_cbase = o.g_cbase; w.KK = o.KK; w.KH = o.KH; w.KW = o.KW;
     w.N = o.N; w.GH = o.GH; w.GW = o.GW; w.QH = o.QH; w.QW = o.QW; w.S = o.S; w.pad = o.pad;
     const int MT = o.M > 32 ? 2 : 1, MB = 32 * MT, PF = (MB / 2) * WGP_PAIR;
     w.XA = (o.pad + 3) & ~3;
     w.RSq = roundup(w.XA + (WGP_BW - 1) * o.S + o.KW - o.pad, 4);
     w.PHq = (WGP_BH - 1) * o.S + o.KH;
-    w.x4 = (o.GW % 4 == 0 && o.QW % 4 == 0 && ((reinterpret_cast<uintptr_t>(o.P) | reinterpret_cast<uintptr_t>(o.Q)) & 15) == 0) ? 1 : 0;
+    w.x4 = (o.GW % 4 == 0 && o.QW % 4 == 0 && (align & 15) == 0) ? 1 : 0;
     const int piece = w.x4 ? 256 : 64;
     w.NPIq = cdiv(w.PHq * w.RSq, piece);
     if (w.NPIq > WGP_MAXQ) return DVF_ERR_UNSUPPORTED;
@@ -1092,7 +1103,7 @@ int wgrad_pipe_segment(const WgradArgs &o, hipStream_t st) {
     const size_t lds = (size_t)2 * (PF + (size_t)CK * w.PSq) * 4;
     if (const char *e = dvf_tune("DVF_WG_DBG")) w.dbg = atoi(e);
     const int rc = dvf_wgrad_pipe_launch(w, MT, NTW, nblocks, lds, st);
-    if (rc == DVF_OK) dvf_plan_note(DVF_K_WGRAD_PIPE, MT, NTW, w.x4, CK, o.S, w.NPIq, nblocks, (int)lds, T, w.RSq, w.PHq);
+    if (rc == DVF_OK) dvf_plan_note(DVF_K_WGRAD_PIPE, MT, NTW, w.x4, CK, o.S, w.NPIq, nblocks, (int)lds, T, w.RSq, nseg);
     return rc;
 }
 
@@ -1143,10 +1154,21 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
     if (!accumulate &&
         hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->C_in * d->C_out * KK, st) != hipSuccess)
         return DVF_ERR_LAUNCH;
+    for (int s = 0; s < nseg; ++s)
+        if (!in_segs[s]) return DVF_ERR_INVALID_ARG;
+    if (!d->transposed) {
+        // one launch over the virtual concatenation: dW[co][ci][a][b] = sum dpre[co][o] * in[ci][o*s - p + (a,b)]
+        WgradArgs a{};
+        a.KK = KK; a.KH = d->KH; a.KW = d->KW; a.N = d->N; a.S = d->stride; a.pad = d->pad; a.G = dw;
+        a.P = dpre; a.PCtot = d->C_out; a.m_base = 0; a.M = d->C_out; a.GH = d->H_out; a.GW = d->W_out;
+        a.Cq = d->C_in; a.QH = d->H_in; a.QW = d->W_in;
+        a.g_mstride = (int64_t)d->C_in * KK; a.g_mbase = 0; a.g_cbase = 0;
+        const int prc = wgrad_pipe_op(a, in_segs, seg_channels, nseg, st);
+        if (prc != DVF_ERR_UNSUPPORTED) return prc;
+    }
     int off = 0;
     for (int s = 0; s < nseg; ++s) {
         const int segc = seg_channels[s];
-        if (!in_segs[s]) return DVF_ERR_INVALID_ARG;
         WgradArgs a{};
         a.KK = KK; a.KH = d->KH; a.KW = d->KW; a.N = d->N; a.S = d->stride; a.pad = d->pad; a.G = dw;
         if (!d->transposed) {
@@ -1159,9 +1181,8 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
             a.P = in_segs[s]; a.PCtot = segc; a.m_base = 0; a.M = segc; a.GH = d->H_in; a.GW = d->W_in;
             a.Q = dpre; a.QCtot = d->C_out; a.q_base = 0; a.Cq = d->C_out; a.QH = d->H_out; a.QW = d->W_out;
             a.g_mstride = (int64_t)d->C_out * KK; a.g_mbase = off; a.g_cbase = 0;
-        }
-        {
-            const int prc = wgrad_pipe_segment(a, st);
+            const int qc = d->C_out;
+            const int prc = wgrad_pipe_op(a, &dpre, &qc, 1, st);
             if (prc == DVF_OK) { off += segc; continue; }
             if (prc != DVF_ERR_UNSUPPORTED) return prc;
         }

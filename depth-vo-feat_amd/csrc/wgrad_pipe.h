@@ -8,9 +8,11 @@
 
 struct WgpArgs {
     const float *P;      // [N, PCtot, GH, GW]; channels m_base .. m_base+M-1 are used
-    const float *Q;      // [N, QCtot, QH, QW]; channels q_base .. q_base+Cq-1 are used
+    const float *Q[DVF_MAX_SEGS];   // virtual concatenation of nseg tensors [N, segC[s], QH, QW]: Cq = sum of segC
+    int segC[DVF_MAX_SEGS];
+    int nseg;
     float *G;            // G[(g_mbase + m) * g_mstride + (g_cbase + c) * KK + tap]
-    int PCtot, m_base, M, QCtot, q_base, Cq;
+    int PCtot, m_base, M, Cq;
     int64_t g_mstride;
     int g_mbase, g_cbase, KK, KH, KW;
     int N, GH, GW, QH, QW, S, pad;

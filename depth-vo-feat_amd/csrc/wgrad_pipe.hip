@@ -45,9 +45,9 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
 
     if (wave >= 4) {
         // ================================================================== producers: all LDS-DMA loads
-        // producers 2*par and 2*par+1 share the items of parity `par`, half the pieces each; a producer never has more
-        // than one item in flight, so "my item has landed" is a plain vmcnt(0)
-        const int pidx = wave - 4, par = pidx >> 1, half = pidx & 1;
+        // the four producers (one per SIMD) take a quarter of the pieces of every item each; two LDS stages, so a
+        // producer never has more than one item in flight and "my share has landed" is a plain vmcnt(0)
+        const int pidx = wave - 4;
         const int planeP = a.GH * a.GW, planeQ = a.QH * a.QW;
         unsigned p_off[4];
         int p_row[4], p_col[4];
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
                 }
             }
         }
-        const __amdgpu_buffer_rsrc_t rs_p = tensor_rsrc(a.P), rs_q = tensor_rsrc(a.Q);
+        const __amdgpu_buffer_rsrc_t rs_p = tensor_rsrc(a.P);
         const int txy = a.tilesX * a.tilesY;
         int n = tile / txy;
         int tY = (tile - n * txy) / a.tilesX;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
             const int nch = min(a.CK, a.Cq - c0);
             const int gy0 = tY * WGP_BH, gx0 = tX * WGP_BW;
             if (DVF_DBG(a, 1)) return;
-            // ---- P tile: channel pairs pp = half, half+2, ...
+            // ---- P tile: channel pairs pp = pidx, pidx+4, ...
             {
                 const int mrem = a.M - m0;                         // valid channels of this m-block (> 0)
                 const int npairs = min(MB / 2, (mrem + 1) >> 1);
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
                     pvo[kk] = ((gy0 + p_row[kk] < a.GH) && (gx0 + p_col[kk] < a.GW)) ? p_off[kk] : OOB;
-                for (int pp = half; pp < npairs; pp += 2) {
+                for (int pp = pidx; pp < npairs; pp += 4) {
                     const bool odd_tail = (2 * pp + 1 >= mrem);    // second channel of the pair does not exist
                     const unsigned soff = soff0 + ((unsigned)(2 * pp * planeP) << 2);
                     float *dst = Pst + pp * WGP_PAIR;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
                     }
                 }
             }
-            // ---- Q patch: channels ci = half, half+2, ...
+            // ---- Q patch: channels ci = pidx, pidx+4, ...
             {
                 const int qy0 = gy0 * S - a.pad, qx0 = gx0 * S - a.XA;
                 unsigned qvo[WGP_MAXQ];
@@ -126,9 +126,13 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
                         qvo[kk] = ok ? ((unsigned)(iy * a.QW + ix) << 2) : OOB;
                     }
                 }
-                const unsigned soff0 = (unsigned)((n * a.QCtot + a.q_base + c0) * planeQ) << 2;
-                for (int ci = half; ci < nch; ci += 2) {
-                    const unsigned soff = soff0 + ((unsigned)(ci * planeQ) << 2);
+                // virtual concatenation: channel c0 + ci of the chunk lives in segment `seg` at channel vc - seg_first
+                int seg = 0, seg_first = 0;
+                for (int ci = pidx; ci < nch; ci += 4) {
+                    const int vc = c0 + ci;
+                    while (vc >= seg_first + a.segC[seg]) { seg_first += a.segC[seg]; ++seg; }
+                    const __amdgpu_buffer_rsrc_t rs_q = tensor_rsrc(a.Q[seg]);
+                    const unsigned soff = (unsigned)((n * a.segC[seg] + (vc - seg_first)) * planeQ) << 2;
                     float *dst = Qst + ci * a.PSq;
                     if (a.x4) {
 #pragma unroll
@@ -153,16 +157,15 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
             if (tile == a.ntiles) { tile = 0; n = 0; ++mc; }
         };
         // item x lives in stage x & 1 and is issued one item ahead
-        if (par == 0) issue(0);
+        issue(0);
         advance();
         for (int x = 0; x < nitems; ++x) {
             // item x must have landed before anyone passes this barrier; item x-1 is fully consumed after it, which frees
             // the stage item x+1 goes to
-            if ((x & 1) == par) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            const int nx = x + 1;
-            if (nx < nitems) {
-                if ((nx & 1) == par) issue(nx & 1);
+            if (x + 1 < nitems) {
+                issue((x + 1) & 1);
                 advance();
             }
         }
