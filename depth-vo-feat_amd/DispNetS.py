@@ -4,7 +4,9 @@ Same class name, constructor arguments, ``forward`` / ``init_weights`` contract 
 (``conv1.0.weight`` ... ``predict_disp1.0.bias``), so checkpoints interchange.  Every convolution runs on the
 hand-written fp32-MFMA kernels of ``libdvf_hip.so`` with bias + ReLU / alpha*sigmoid+beta fused in the
 epilogue; ``torch.cat`` is replaced by virtual concatenation inside the consuming kernel, ``crop_like`` by
-never computing the cropped pixels, and the disparity up-sampling by a dedicated kernel.
+never computing the cropped pixels, and the disparity up-sampling by a dedicated kernel.  Every ReLU layer's output is
+consumed by convolutions only (the next layer, a skip into an iconv, a predict_disp head), so all of them are declared
+``fuse_bwd``: the consumers' dgrad kernels apply relu' and sum the bias gradient (dvf/conv.py::ReluTag).
 """
 import torch
 import torch.nn as nn
@@ -34,16 +36,16 @@ class DispNetS(nn.Module):
         cin = 3
         for i, (co, k) in enumerate(zip(_ENC_PLANES, _ENC_KERNEL), start=1):
             p = (k - 1) // 2
-            setattr(self, f"conv{i}", _pair(None, FusedConv2d(cin, co, k, 2, p, _L.ACT_RELU),
-                                            FusedConv2d(co, co, k, 1, p, _L.ACT_RELU)))
+            setattr(self, f"conv{i}", _pair(None, FusedConv2d(cin, co, k, 2, p, _L.ACT_RELU, fuse_bwd=True),
+                                            FusedConv2d(co, co, k, 1, p, _L.ACT_RELU, fuse_bwd=True)))
             cin = co
         up_in = (_ENC_PLANES[6],) + _DEC_PLANES[:-1]
         skip = (_ENC_PLANES[5], _ENC_PLANES[4], _ENC_PLANES[3], _ENC_PLANES[2], 1 + _ENC_PLANES[1], 1 + _ENC_PLANES[0], 1)
         for j, lvl in enumerate(range(7, 0, -1)):
             setattr(self, f"upconv{lvl}", _pair(None, FusedConvTranspose2d(up_in[j], _DEC_PLANES[j], 3, 2, 1, _L.ACT_RELU,
-                                                                         output_padding=1)))
+                                                                         output_padding=1, fuse_bwd=True)))
             setattr(self, f"iconv{lvl}", _pair(None, FusedConv2d(_DEC_PLANES[j] + skip[j], _DEC_PLANES[j], 3, 1, 1,
-                                                                _L.ACT_RELU)))
+                                                                _L.ACT_RELU, fuse_bwd=True)))
         for lvl, ci in zip((4, 3, 2, 1), _DEC_PLANES[3:]):
             setattr(self, f"predict_disp{lvl}", _pair(None, FusedConv2d(ci, 1, 3, 1, 1, _L.ACT_SIGMOID_AFFINE,
                                                                        alpha=alpha, beta=beta)))

@@ -19,14 +19,14 @@ class _PoseExpBase(nn.Module):
     def _build(self, in_planes, n_pose_out, nb_masks, output_exp):
         cin = in_planes
         for i, (co, k) in enumerate(zip(_ENC_PLANES, _ENC_KERNEL), start=1):
-            setattr(self, f"conv{i}", nn.Sequential(FusedConv2d(cin, co, k, 2, (k - 1) // 2, _L.ACT_RELU), FusedAct()))
+            setattr(self, f"conv{i}", nn.Sequential(FusedConv2d(cin, co, k, 2, (k - 1) // 2, _L.ACT_RELU, fuse_bwd=True), FusedAct()))
             cin = co
         self.pose_pred = FusedConv2d(_ENC_PLANES[6], n_pose_out, 1, 1, 0)
         if output_exp:
             up_in = (_ENC_PLANES[4],) + _DEC_PLANES[:-1]
             for j, lvl in enumerate(range(5, 0, -1)):
                 setattr(self, f"upconv{lvl}", nn.Sequential(
-                    FusedConvTranspose2d(up_in[j], _DEC_PLANES[j], 4, 2, 1, _L.ACT_RELU), FusedAct()))
+                    FusedConvTranspose2d(up_in[j], _DEC_PLANES[j], 4, 2, 1, _L.ACT_RELU, fuse_bwd=True), FusedAct()))
             for lvl, ci in zip((4, 3, 2, 1), _DEC_PLANES[1:]):
                 setattr(self, f"predict_mask{lvl}", FusedConv2d(ci, nb_masks, 3, 1, 1, _L.ACT_SIGMOID_AFFINE))
 

@@ -1041,7 +1041,10 @@ int dgrad_segment_unpacked(const dvf_conv_desc *d, const float *dpre, const floa
 // Plan + launch of the pipelined weight-gradient kernel (wgrad_pipe.hip) for one segment; DVF_ERR_UNSUPPORTED when the
 // geometry is outside its envelope (the register-staged conv_wgrad_kernel then takes the segment).
 static int roundup(int v, int q) { return (v + q - 1) / q * q; }
-int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qsegc, int nseg, hipStream_t st) {
+// dbias != NULL (Conv2d roles only): also dbias[m] += sum of P[m]; *bias_done says whether the launch took it.
+int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qsegc, int nseg, hipStream_t st, float *dbias = nullptr,
+                  bool *bias_done = nullptr) {
+    if (bias_done) *bias_done = false;
     static const bool off = dvf_tune("DVF_WG_PIPE") && atoi(dvf_tune("DVF_WG_PIPE")) == 0;     // tuning knob
     if (off) return DVF_ERR_UNSUPPORTED;
     const int T = o.KH * o.KW;
@@ -1079,7 +1082,7 @@ int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qseg
     for (int ntw = 2; ntw >= 1; --ntw) {
         int ckmax = (128 * ntw) / T;
         if (ckmax > o.Cq) ckmax = o.Cq;
-        while (ckmax >= 1 && (size_t)2 * (PF + (size_t)ckmax * w.PSq) * 4 > WGP_LDS_CAP) --ckmax;
+        while (ckmax >= 1 && (size_t)2 * (PF + (size_t)(ckmax + 1) * w.PSq) * 4 > WGP_LDS_CAP) --ckmax;   // (+1: slot of ones)
         if (ckmax < 1) continue;
         const int nch = cdiv(o.Cq, ckmax), cost = nch * ntw;
         if (cost < best_cost) { best_cost = cost; NTW = ntw; CK = cdiv(o.Cq, nch); }
@@ -1100,10 +1103,14 @@ int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qseg
         return n;
     }();
     const int nblocks = w.W < ncu ? w.W : ncu;
-    const size_t lds = (size_t)2 * (PF + (size_t)CK * w.PSq) * 4;
+    w.bias_col = (dbias && CK * T < 128 * NTW) ? CK * T : -1;      // a spare column of the tile multiplies by ones
+    w.dbias = w.bias_col >= 0 ? dbias : nullptr;
+    w.QSLOTS = CK + (w.bias_col >= 0 ? 1 : 0);
+    const size_t lds = (size_t)2 * (PF + (size_t)w.QSLOTS * w.PSq) * 4;
     if (const char *e = dvf_tune("DVF_WG_DBG")) w.dbg = atoi(e);
     const int rc = dvf_wgrad_pipe_launch(w, MT, NTW, nblocks, lds, st);
     if (rc == DVF_OK) dvf_plan_note(DVF_K_WGRAD_PIPE, MT, NTW, w.x4, CK, o.S, w.NPIq, nblocks, (int)lds, T, w.RSq, nseg);
+    if (rc == DVF_OK && bias_done) *bias_done = w.bias_col >= 0;
     return rc;
 }
 
@@ -1137,8 +1144,29 @@ int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, 
     return dvf_conv2d_dgrad_ws(d, dpre, w, din_segs, seg_channels, nseg, nullptr, 0, stream);
 }
 
+static int wgrad_impl(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg, const float *dpre,
+                      float *dw, int accumulate, float *dbias, bool *bias_done, void *stream);
+
 int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
                      const float *dpre, float *dw, int accumulate, void *stream) {
+    return wgrad_impl(d, in_segs, seg_channels, nseg, dpre, dw, accumulate, nullptr, nullptr, stream);
+}
+
+int dvf_conv2d_wgrad_bias(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                          const float *dpre, float *dw, int accumulate, float *dbias, int accumulate_dbias, void *stream) {
+    if (!dbias || !d) return DVF_ERR_INVALID_ARG;
+    hipStream_t st = dvf_stream(stream);
+    if (!accumulate_dbias && hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)(d->C_out > 0 ? d->C_out : 0), st) != hipSuccess)
+        return DVF_ERR_LAUNCH;
+    bool done = false;
+    const int rc = wgrad_impl(d, in_segs, seg_channels, nseg, dpre, dw, accumulate, dbias, &done, stream);
+    if (rc || done) return rc;
+    // the weight-gradient launch had no spare column (or ran another kernel): one pass over dpre
+    return dvf_act_bwd2(dpre, nullptr, nullptr, dbias, d->N, d->C_out, d->H_out * d->W_out, DVF_ACT_NONE, 1.f, 0.f, 1, stream);
+}
+
+static int wgrad_impl(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg, const float *dpre,
+                      float *dw, int accumulate, float *dbias, bool *bias_done, void *stream) {
     dvf_plan_reset();
     int rc = check_desc(d);
     if (rc) return rc;
@@ -1163,7 +1191,7 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
         a.P = dpre; a.PCtot = d->C_out; a.m_base = 0; a.M = d->C_out; a.GH = d->H_out; a.GW = d->W_out;
         a.Cq = d->C_in; a.QH = d->H_in; a.QW = d->W_in;
         a.g_mstride = (int64_t)d->C_in * KK; a.g_mbase = 0; a.g_cbase = 0;
-        const int prc = wgrad_pipe_op(a, in_segs, seg_channels, nseg, st);
+        const int prc = wgrad_pipe_op(a, in_segs, seg_channels, nseg, st, dbias, bias_done);
         if (prc != DVF_ERR_UNSUPPORTED) return prc;
     }
     int off = 0;
@@ -1392,6 +1420,57 @@ int dvf_conv2d_fwd_packed(const dvf_conv_desc *d, const float *const *in_segs, c
     return pipe_run(op, packed, ws, ws_floats, dvf_stream(stream));
 }
 
+// dgrad of every requested segment; packed == NULL: unpacked kernels only.  mask_segs[s] != NULL: segment s was produced
+// by a ReLU layer whose output is mask_segs[s]; its gradient leaves already multiplied by relu'() and its channel sums are
+// added to dbias_segs[s] (fused in the pipelined kernel / its split-K finish, a pass of act_bwd_kernel after the others).
+static int dgrad_all(const dvf_conv_desc *d, const float *dpre, const float *packed, const float *w, float *const *din_segs,
+                     const int *seg_channels, int nseg, float *ws, int64_t ws_floats, const float *const *mask_segs,
+                     float *const *dbias_segs, hipStream_t st) {
+    const int HWin = d->H_in * d->W_in;
+    auto postpass = [&](int s) -> int {
+        if (!mask_segs || !mask_segs[s] || !din_segs[s]) return DVF_OK;
+        return dvf_act_bwd2(din_segs[s], mask_segs[s], din_segs[s], dbias_segs ? dbias_segs[s] : nullptr, d->N, seg_channels[s],
+                            HWin, DVF_ACT_RELU, 1.f, 0.f, 1, st);
+    };
+    if (dvf_head_applicable(d, nseg)) {
+        if (!din_segs[0]) return DVF_OK;
+        if (!w) return DVF_ERR_INVALID_ARG;
+        const int rc = dvf_head_dgrad(d, dpre, w, din_segs[0], st);
+        return rc ? rc : postpass(0);
+    }
+    PipeOp op;
+    int off = 0;
+    for (int s = 0; s < nseg; ++s) {
+        int rc = DVF_ERR_UNSUPPORTED;
+        int64_t nf = 0;
+        if (packed) {
+            rc = make_dgrad_op(d, dpre, din_segs[s], off, seg_channels[s], op);
+            if (rc) return rc;
+            rc = pipe_pack(op, nullptr, nullptr, &nf, nullptr, nullptr);      // plan only: is this segment packed?
+            if (rc && rc != DVF_ERR_UNSUPPORTED) return rc;
+        }
+        if (rc == DVF_ERR_UNSUPPORTED) {                                      // narrow segment: unpacked kernels
+            if (din_segs[s]) {
+                if (!w) return DVF_ERR_INVALID_ARG;
+                rc = dgrad_segment_unpacked(d, dpre, w, din_segs[s], off, seg_channels[s], st, ws, ws_floats);
+                if (rc) return rc;
+                rc = postpass(s);
+                if (rc) return rc;
+            }
+        } else {
+            if (din_segs[s]) {
+                op.a.mask = (mask_segs && mask_segs[s]) ? mask_segs[s] : nullptr;
+                op.a.dbias = (op.a.mask && dbias_segs) ? dbias_segs[s] : nullptr;
+                rc = pipe_run(op, packed, ws, ws_floats, st);
+                if (rc) return rc;
+            }
+            packed += nf;
+        }
+        off += seg_channels[s];
+    }
+    return DVF_OK;
+}
+
 int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const float *packed, const float *w,
                             float *const *din_segs, const int *seg_channels, int nseg, float *ws, int64_t ws_floats,
                             void *stream) {
@@ -1401,30 +1480,20 @@ int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const flo
     rc = check_segs(d, seg_channels, nseg);
     if (rc) return rc;
     if (!dpre || !packed || !din_segs) return DVF_ERR_INVALID_ARG;
-    PipeOp op;
-    int off = 0;
-    for (int s = 0; s < nseg; ++s) {
-        rc = make_dgrad_op(d, dpre, din_segs[s], off, seg_channels[s], op);
-        if (rc) return rc;
-        int64_t nf = 0;
-        rc = pipe_pack(op, nullptr, nullptr, &nf, nullptr, nullptr);      // plan only: is this segment packed?
-        if (rc && rc != DVF_ERR_UNSUPPORTED) return rc;
-        if (rc == DVF_ERR_UNSUPPORTED) {                                  // narrow segment: unpacked kernels
-            if (din_segs[s]) {
-                if (!w) return DVF_ERR_INVALID_ARG;
-                rc = dgrad_segment_unpacked(d, dpre, w, din_segs[s], off, seg_channels[s], dvf_stream(stream), ws, ws_floats);
-                if (rc) return rc;
-            }
-        } else {
-            if (din_segs[s]) {
-                rc = pipe_run(op, packed, ws, ws_floats, dvf_stream(stream));
-                if (rc) return rc;
-            }
-            packed += nf;
-        }
-        off += seg_channels[s];
-    }
-    return DVF_OK;
+    if (dvf_head_applicable(d, nseg)) return DVF_ERR_UNSUPPORTED;
+    return dgrad_all(d, dpre, packed, w, din_segs, seg_channels, nseg, ws, ws_floats, nullptr, nullptr, dvf_stream(stream));
+}
+
+int dvf_conv2d_dgrad_masked(const dvf_conv_desc *d, const float *dpre, const float *packed, const float *w,
+                            float *const *din_segs, const int *seg_channels, int nseg, float *ws, int64_t ws_floats,
+                            const float *const *mask_segs, float *const *dbias_segs, void *stream) {
+    dvf_plan_reset();
+    int rc = check_desc(d);
+    if (rc) return rc;
+    rc = check_segs(d, seg_channels, nseg);
+    if (rc) return rc;
+    if (!dpre || !din_segs || !mask_segs || (!packed && !w)) return DVF_ERR_INVALID_ARG;
+    return dgrad_all(d, dpre, packed, w, din_segs, seg_channels, nseg, ws, ws_floats, mask_segs, dbias_segs, dvf_stream(stream));
 }
 
 

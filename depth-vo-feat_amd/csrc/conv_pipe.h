@@ -64,6 +64,10 @@ struct PipeArgs {
     int lsw, lsh, TGX, TGY, BW, BH, BN, tilesX, tilesY;
     int SLmax, PSRmax, NST;               // LDS carve per stage (NST = 2 or 3 stages): SLmax weight floats | CK * PSRmax patch floats
     int dbg;                              // ablation switches (tools/conv_bench.py): 1 no patch loads, 2 no weight loads, 4 no MFMA
+    // dgrad of a segment produced by a ReLU layer (out_mode 0): out = (mask > 0) ? v : 0 and dbias[channel] += sum(out) --
+    // the activation backward pass and the bias gradient of the PRODUCING layer, done where its gradient is born
+    const float *mask;                    // same shape as out (the producing layer's output), or NULL
+    float *dbias;                         // [M] accumulated with float atomics, or NULL
 };
 
 __host__ __device__ inline int pipe_row_stride(int RSu, int SW, int SH, int IS) {
@@ -381,6 +385,56 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
     const int m0 = mb * (32 * MTW) + wm * (32 * MT);
     float *outp = a.out + (a.out_mode == 2 ? (int64_t)ks * a.ws_slice : 0);
     const int64_t HW = (int64_t)a.OH * a.OW;
+    if (a.mask && a.out_mode == 0) {
+        // ReLU backward of the producing layer + its bias gradient (no bias / activation of this op: it is a dgrad)
+        float csum[MT][16];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) csum[m][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int oy = oy0 + opy[i], ox = ox0 + opx[i], n = n0 + opn[i];
+            const int Y = oy * a.OS + c.py, X = ox * a.OS + c.px;
+            const bool pok = (oy < c.OHc) && (ox < c.OWc) && (Y < a.OH) && (X < a.OW) && (opn[i] < a.BN) && (n < a.N);
+            const int64_t base = ((int64_t)n * a.M + m0 + 4 * kh) * HW + (int64_t)Y * a.OW + X;
+            // all mask loads of the tile first (no branch around them: invalid elements read element 0), then the stores
+            float mk[MT][16];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = m * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool ok = pok && (m0 + 4 * kh + ml < a.M);
+                    mk[m][r] = a.mask[ok ? base + (int64_t)ml * HW : 0];
+                }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = m * 32 + (r & 3) + 8 * (r >> 2);
+                    if (pok && m0 + 4 * kh + ml < a.M) {
+                        const float v = mk[m][r] > 0.f ? acc[m][i][r] : 0.f;
+                        outp[base + (int64_t)ml * HW] = v;
+                        csum[m][r] += v;
+                    }
+                }
+            }
+        }
+        if (a.dbias) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float sv = csum[m][r];
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) sv += __shfl_xor(sv, off, 64);   // over the 32 pixels of this half-wave
+                    const int mm = m0 + 4 * kh + m * 32 + (r & 3) + 8 * (r >> 2);
+                    if (nl == 0 && mm < a.M) atomicAdd(a.dbias + mm, sv);
+                }
+        }
+        return;
+    }
     float bv[MT][16];
 #pragma unroll
     for (int m = 0; m < MT; ++m)

@@ -168,6 +168,31 @@ __global__ void splitk_reduce_kernel(const float *ws, float *out, const float *b
     }
 }
 
+// Split-K finish of a dgrad whose segment was produced by a ReLU layer: out = (mask > 0) ? sum_k ws[k] : 0 and
+// dbias[c] += sum(out).  One block per chunk of one (n, c) plane: fixed-order sum of the partial tiles, one atomic per block.
+__global__ __launch_bounds__(256) void splitk_reduce_mask_kernel(const float *ws, float *out, const float *mask, float *dbias,
+                                                                 int KS, int64_t slice, int C, int HW, int chunks) {
+    __shared__ float red[4];
+    const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
+    const int per = (HW + chunks - 1) / chunks;
+    const int lo = chunk * per, hi = min(HW, lo + per);
+    const int64_t base = (int64_t)plane * HW;
+    float s = 0.f;
+    for (int e = lo + threadIdx.x; e < hi; e += 256) {
+        const int64_t i = base + e;
+        float v = ws[i];
+        for (int k = 1; k < KS; ++k) v += ws[i + k * slice];
+        v = mask[i] > 0.f ? v : 0.f;
+        out[i] = v;
+        s += v;
+    }
+    if (!dbias) return;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dbias + plane % C, red[0] + red[1] + red[2] + red[3]);
+}
+
 // ---------------------------------------------------------------------------------------- host planning
 struct PipePlan {
     int MT, NT, WM, CKH, TBU, threads;
@@ -397,7 +422,13 @@ int pipe_run(PipeOp &op, const float *packed, float *ws, int64_t ws_floats, hipS
     rc = launch_pipe(a, pl, st);
     if (rc) return rc;
     const int64_t nb = (total + 255) / 256;
-    if (mode == 2) {
+    if (mode == 2 && a.mask) {
+        int chunks = 1;
+        const int64_t planes = (int64_t)a.N * a.M;
+        while (planes * chunks < 1024 && HW / (chunks * 2) >= 256) chunks *= 2;
+        splitk_reduce_mask_kernel<<<(unsigned)(planes * chunks), 256, 0, st>>>(ws, out, a.mask, a.dbias, a.KS, total, a.M, (int)HW, chunks);
+        DVF_LAUNCH_CHECK();
+    } else if (mode == 2) {
         splitk_reduce_kernel<<<(int)(nb > 4096 ? 4096 : nb), 256, 0, st>>>(ws, out, a.bias, a.KS, total, a.M, HW, a.act,
                                                                           a.alpha, a.beta);
         DVF_LAUNCH_CHECK();
@@ -405,6 +436,8 @@ int pipe_run(PipeOp &op, const float *packed, float *ws, int64_t ws_floats, hipS
         bias_act_kernel<<<(int)(nb > 2048 ? 2048 : nb), 256, 0, st>>>(out, a.bias, a.M, HW, total, a.act, a.alpha, a.beta);
         DVF_LAUNCH_CHECK();
     }
+    if (mode == 1 && a.mask)    // atomic accumulation into a zeroed output: the mask pass runs over the finished sums
+        return dvf_act_bwd2(out, a.mask, out, a.dbias, a.N, a.M, (int)HW, DVF_ACT_RELU, 1.f, 0.f, 1, st);
     return DVF_OK;
 }
 

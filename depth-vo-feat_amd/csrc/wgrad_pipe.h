@@ -21,6 +21,9 @@ struct WgpArgs {
     int PHq, RSq, PSq, NPIq, XA;   // Q patch: rows, row stride, channel stride (floats), DMA pieces per channel, aligned left margin
     int x4;              // 1: 16-byte DMA lanes (GW % 4 == 0, QW % 4 == 0, 16-byte aligned bases), 0: 4-byte lanes
     int W;               // work items = mtiles * cchunks * ntiles, split evenly over the blocks of the launch
+    float *dbias;        // bias gradient of a Conv2d layer (P = dL/dpre): dbias[m] += sum over pixels of P[m], or NULL
+    int bias_col;        // column of the block's tile that multiplies P by a slot of ones (-1: none); QSLOTS = CK + 1 then
+    int QSLOTS;          // channel slots of PSq floats per LDS stage
     int dbg;             // ablation switches (-DDVF_TUNING builds): 1 no DMA loads, 4 no MFMA, 8 no atomic epilogue
 };
 

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, nl = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int stage_floats = PF + a.CK * a.PSq;
+    const int stage_floats = PF + a.QSLOTS * a.PSq;
     const int nb = gridDim.x, b = blockIdx.x;
     const int w0 = (int)(((int64_t)a.W * b) / nb), w1 = (int)(((int64_t)a.W * (b + 1)) / nb);
     const int nitems = w1 - w0;
@@ -183,6 +183,16 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
         loff[u] = in_chunk ? cj * a.PSq + ta * a.RSq + tb + (a.XA - a.pad) : 0;
         cjv[u] = in_chunk ? cj : -1;
         tjv[u] = tj;
+        if (j == a.bias_col) {             // bias gradient: this column reads the slot of ones behind the chunk's channels
+            loff[u] = a.CK * a.PSq;
+            cjv[u] = -2;
+        }
+    }
+    if (a.bias_col >= 0) {                 // (visible to the MFMA waves after the first barrier; the DMA never writes it)
+        for (int e = tid; e < a.PSq; e += 256) {
+            smem[PF + a.CK * a.PSq + e] = 1.f;
+            smem[stage_floats + PF + a.CK * a.PSq + e] = 1.f;
+        }
     }
     f32x16 acc[MT][NTW];
 #pragma unroll
@@ -245,6 +255,7 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
 #pragma unroll
         for (int u = 0; u < NTW; ++u) {
             const bool colok = cjv[u] >= 0 && cjv[u] < nch;
+            const bool biascol = cjv[u] == -2 && cb == 0;          // (every chunk computes it; chunk 0 delivers it)
             const int64_t gcol = (int64_t)(a.g_cbase + c0 + cjv[u]) * a.KK + tjv[u];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -253,6 +264,7 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
                     const int mm = m0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                     if (colok && mm < a.M && !DVF_DBG(a, 8))
                         atomicAdd(a.G + (int64_t)(a.g_mbase + mm) * a.g_mstride + gcol, acc[m][u][r]);
+                    if (biascol && mm < a.M) atomicAdd(a.dbias + mm, acc[m][u][r]);
                     acc[m][u][r] = 0.f;
                 }
         }

@@ -156,6 +156,15 @@ def _packed_weights(weight, holder, desc, segc, kind):
 
 
 GEOM_LOG = None   # set to a list(): ConvFn.forward appends the geometry of every call (tests: bench-shape parity)
+FUSE_RELU_BWD = True   # False: every layer runs its own activation backward pass (dvf_act_bwd2), as in round 1
+
+
+class ReluTag:
+    """Carried by the output y of a ReLU convolution whose module was declared ``fuse_bwd`` (EVERY consumer of y is a
+    ConvFn): the consumers' dgrad kernels then deliver dL/dy already multiplied by relu'(y) -- the producing layer runs no
+    activation backward pass, and its bias gradient is one more column of its weight-gradient GEMM (dvf_conv2d_wgrad_bias).  relu' is a 0/1
+    mask, so masking each consumer's contribution equals masking their sum."""
+    __slots__ = ()
 
 
 class ConvFn(torch.autograd.Function):
@@ -163,7 +172,9 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight, bias, cfg, *inputs):
-        k, stride, pad, opad, transposed, act, alpha, beta, out_hw = cfg
+        k, stride, pad, opad, transposed, act, alpha, beta, out_hw = cfg[:9]
+        ctx.out_tag = cfg[9] if len(cfg) > 9 else None      # ReluTag of this layer's own output (module declared fuse_bwd)
+        ctx.in_tags = [getattr(x, "_dvf_relu_tag", None) for x in inputs]
         # parameters owned by a FlatAdam arena: their gradients are added in place (dvf/engine.py)
         ctx.wparam = weight if getattr(weight, "_dvf_grad", None) is not None else None
         ctx.bparam = bias if (bias is not None and getattr(bias, "_dvf_grad", None) is not None) else None
@@ -185,7 +196,7 @@ class ConvFn(torch.autograd.Function):
             oh, ow = min(oh, out_hw[0]), min(ow, out_hw[1])
         desc = L.ConvDesc(N, cin, H, W, cout, oh, ow, k, k, stride, pad, 1 if transposed else 0, act, alpha, beta)
         if GEOM_LOG is not None:
-            GEOM_LOG.append((tuple(segc), cout, cfg, (N, H, W), tuple(ctx.needs_input_grad[3:])))
+            GEOM_LOG.append((tuple(segc), cout, tuple(cfg[:9]), (N, H, W), tuple(ctx.needs_input_grad[3:])))
         out = torch.empty((N, cout, oh, ow), device=weight.device, dtype=torch.float32)
         # algorithmic MACs of this layer: kept pixels x taps actually contributing
         taps = k * k / (stride * stride) if transposed else k * k
@@ -222,7 +233,12 @@ class ConvFn(torch.autograd.Function):
         # a bias owned by a FlatAdam arena: its gradient slice is zero after zero_grad(), add the channel sums in place
         acc_b = need_b and ctx.bparam is not None
         dbias = (ctx.bparam._dvf_grad if acc_b else torch.empty(cout, device=out.device)) if need_b else None
-        if desc.act != L.ACT_NONE:
+        fused_out = ctx.out_tag is not None
+        if fused_out:
+            # every consumer's dgrad already applied relu'(y) and accumulated the bias gradient into the tag's buffer
+            # (the bias gradient rides on the weight-gradient kernel below: one more column, of ones)
+            dpre = gout
+        elif desc.act != L.ACT_NONE:
             dpre = torch.empty_like(gout)
             with L.timed("act_bwd", 0.0, 12.0 * gout.numel()):
                 L.check(lib.dvf_act_bwd2(L.dev(gout, "grad_out"), L.dev(out), L.dev(dpre), L.dev(dbias), N, cout, oh * ow,
@@ -236,20 +252,33 @@ class ConvFn(torch.autograd.Function):
         if any(need_in):
             frac = sum(c for c, need in zip(segc, need_in) if need) / float(sum(segc))
             packed, ws = _packed_weights(weight, ctx.holder, desc, segc, 1)
+            masked = [t is not None and need for t, need in zip(ctx.in_tags, need_in)]
             with L.timed("conv_dgrad", 2 * ctx.macs * frac, tag=ctx.tag):
-                rc = L.ERR_UNSUPPORTED
-                if packed is not None:
-                    rc = lib.dvf_conv2d_dgrad_packed(ctypes.byref(desc), L.dev(dpre), L.dev(packed), L.dev(weight),
-                                                     L.ptr_array(gins), L.int_array(segc), len(segc), L.dev(ws),
-                                                     ws.numel() if ws is not None else 0, L.stream())
-                    if rc != L.ERR_UNSUPPORTED:
-                        L.check(rc, "dvf_conv2d_dgrad_packed")
-                if rc == L.ERR_UNSUPPORTED:
-                    L.check(lib.dvf_conv2d_dgrad_ws(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins),
-                                                    L.int_array(segc), len(segc), L.dev(ws),
-                                                    ws.numel() if ws is not None else 0, L.stream()), "dvf_conv2d_dgrad_ws")
+                if any(masked):
+                    # segments produced by fuse_bwd ReLU layers: their gradient leaves masked, their bias gradient summed
+                    masks = [x if m else None for x, m in zip(inputs, masked)]
+                    dbs = [None] * len(masks)
+                    L.check(lib.dvf_conv2d_dgrad_masked(ctypes.byref(desc), L.dev(dpre), L.dev(packed), L.dev(weight),
+                                                        L.ptr_array(gins), L.int_array(segc), len(segc), L.dev(ws),
+                                                        ws.numel() if ws is not None else 0, L.ptr_array(masks),
+                                                        L.ptr_array(dbs), L.stream()), "dvf_conv2d_dgrad_masked")
+                else:
+                    rc = L.ERR_UNSUPPORTED
+                    if packed is not None:
+                        rc = lib.dvf_conv2d_dgrad_packed(ctypes.byref(desc), L.dev(dpre), L.dev(packed), L.dev(weight),
+                                                         L.ptr_array(gins), L.int_array(segc), len(segc), L.dev(ws),
+                                                         ws.numel() if ws is not None else 0, L.stream())
+                        if rc != L.ERR_UNSUPPORTED:
+                            L.check(rc, "dvf_conv2d_dgrad_packed")
+                    if rc == L.ERR_UNSUPPORTED:
+                        L.check(lib.dvf_conv2d_dgrad_ws(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins),
+                                                        L.int_array(segc), len(segc), L.dev(ws),
+                                                        ws.numel() if ws is not None else 0, L.stream()), "dvf_conv2d_dgrad_ws")
             L.note_plans("dgrad")
         dw = None
+        if fused_out and need_b and not need_w:     # (frozen weights, trainable bias: one reduction pass over dpre)
+            L.check(lib.dvf_act_bwd2(L.dev(dpre), None, None, L.dev(dbias), N, cout, oh * ow, L.ACT_NONE, 1.0, 0.0,
+                                     1 if acc_b else 0, L.stream()), "dvf_act_bwd2")
         if need_w:
             arena = ctx.wparam is not None
             dw = ctx.wparam._dvf_grad if arena else torch.empty_like(weight)
@@ -257,9 +286,14 @@ class ConvFn(torch.autograd.Function):
             side = ctx.wparam._dvf_owner.fork_wgrad(dpre, *inputs) if arena else None
             with (torch.cuda.stream(side) if side is not None else _NullCtx()):
                 with L.timed("conv_wgrad", 2 * ctx.macs, tag=ctx.tag):
-                    L.check(lib.dvf_conv2d_wgrad(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
-                                                 L.dev(dpre), L.dev(dw), 1 if arena else 0, L.stream()),
-                            "dvf_conv2d_wgrad")
+                    if fused_out and need_b:
+                        L.check(lib.dvf_conv2d_wgrad_bias(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
+                                                          L.dev(dpre), L.dev(dw), 1 if arena else 0, L.dev(dbias),
+                                                          1 if acc_b else 0, L.stream()), "dvf_conv2d_wgrad_bias")
+                    else:
+                        L.check(lib.dvf_conv2d_wgrad(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
+                                                     L.dev(dpre), L.dev(dw), 1 if arena else 0, L.stream()),
+                                "dvf_conv2d_wgrad")
                     L.note_plans("wgrad")
             if arena:
                 ctx.wparam._dvf_owner.grad_ready(ctx.wparam)
@@ -409,8 +443,11 @@ class FusedConv2d(nn.Module):
     transposed = False
 
     def __init__(self, in_planes, out_planes, kernel_size, stride=1, padding=0, act=L.ACT_NONE, alpha=1.0, beta=0.0,
-                 output_padding=0):
+                 output_padding=0, fuse_bwd=False):
+        """fuse_bwd (ReLU layers only): the network GUARANTEES that every consumer of this layer's output is a
+        FusedConv2d / FusedConvTranspose2d taking the returned tensor itself (no view, no other op) -- see ReluTag."""
         super().__init__()
+        self.fuse_bwd = bool(fuse_bwd) and act == L.ACT_RELU
         self.k, self.stride, self.pad, self.opad = kernel_size, stride, padding, output_padding
         self.act, self.alpha, self.beta = act, float(alpha), float(beta)
         self.in_planes, self.out_planes = in_planes, out_planes
@@ -428,8 +465,14 @@ class FusedConv2d(nn.Module):
             self.bias.uniform_(-bound, bound)
 
     def forward(self, *inputs, out_hw=None):
-        cfg = (self.k, self.stride, self.pad, self.opad, self.transposed, self.act, self.alpha, self.beta, out_hw)
-        return ConvFn.apply(self.weight, self.bias, cfg, *inputs)
+        tag = None
+        if self.fuse_bwd and FUSE_RELU_BWD and torch.is_grad_enabled() and self.bias.requires_grad and inputs[0].is_cuda:
+            tag = ReluTag()
+        cfg = (self.k, self.stride, self.pad, self.opad, self.transposed, self.act, self.alpha, self.beta, out_hw, tag)
+        out = ConvFn.apply(self.weight, self.bias, cfg, *inputs)
+        if tag is not None:
+            out._dvf_relu_tag = tag
+        return out
 
     def extra_repr(self):
         return (f"{self.in_planes}, {self.out_planes}, kernel_size={self.k}, stride={self.stride}, padding={self.pad}, "

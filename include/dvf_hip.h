@@ -185,6 +185,11 @@ int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, 
 /* d(loss)/d(w) in w's own layout; accumulate != 0 adds to dw, otherwise dw is zeroed first. */
 int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
                      const float *dpre, float *dw, int accumulate, void *stream);
+/* dvf_conv2d_wgrad + the bias gradient of the same layer, dbias[c] (+)= sum over (n, y, x) of dpre[n][c][y][x]
+ * (torch: the bias output of ConvolutionBackward).  For Conv2d layers the pipelined weight-gradient kernel multiplies its
+ * dpre tile by one more column -- of ones -- so no extra pass reads dpre; otherwise one reduction pass runs after it. */
+int dvf_conv2d_wgrad_bias(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                          const float *dpre, float *dw, int accumulate, float *dbias, int accumulate_dbias, void *stream);
 
 /* Packed-weight fast path: LDS-DMA pipelined kernels that read the weights from a pre-packed copy (the exact LDS
  * image of every reduction chunk), same results as dvf_conv2d_fwd / dvf_conv2d_dgrad.  op_kind 0 = forward,
@@ -202,6 +207,15 @@ int dvf_conv2d_fwd_packed(const dvf_conv_desc *d, const float *const *in_segs, c
 int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const float *packed, const float *w,
                             float *const *din_segs, const int *seg_channels, int nseg, float *ws, int64_t ws_floats,
                             void *stream);
+/* dgrad that also finishes the PRODUCING layers' backward pass.  mask_segs[s] != NULL says input segment s is the output
+ * y of a ReLU convolution (reference: nn.ReLU(inplace=True) after every conv, DispNetS.py:10-16,30-41, PoseExpNet_sfm.py:9-13):
+ * din_segs[s] leaves as (y > 0) ? din : 0 -- which is dL/dpre of that layer when every consumer of y does the same
+ * (the ReLU mask distributes over the sum autograd forms) -- and its sums over (n, y, x) are ADDED to dbias_segs[s][c]
+ * (that layer's bias gradient; float atomics; may be NULL).  packed may be NULL (unpacked kernels only); mask_segs entries
+ * may be NULL (plain dgrad of that segment).  Replaces torch's ThresholdBackward + the bias reduction of ConvolutionBackward. */
+int dvf_conv2d_dgrad_masked(const dvf_conv_desc *d, const float *dpre, const float *packed, const float *w,
+                            float *const *din_segs, const int *seg_channels, int nseg, float *ws, int64_t ws_floats,
+                            const float *const *mask_segs, float *const *dbias_segs, void *stream);
 /* The unpacked entries with a split-K workspace (>= dvf_conv2d_ws_floats(...) floats; NULL = the float-atomic fallback of
  * dvf_conv2d_fwd / dvf_conv2d_dgrad): small grids split the reduction over blocks, and with the workspace the partial
  * tiles are summed in a fixed order -- activations are then bit-reproducible from run to run. */

@@ -112,7 +112,7 @@ def _distinct(geoms):
 def test_every_bench_layer_geometry():
     """Forward / dgrad / wgrad / bias-grad of every distinct convolution geometry of the cfg-2 step at batch 4."""
     from dvf import lib as L
-    from dvf.conv import ConvFn
+    from dvf.conv import ConvFn, ReluTag
     if "geoms" not in STATE:
         test_fullsize_step_vs_oracle()
     geoms = _distinct(STATE["geoms"])
@@ -155,6 +155,39 @@ def test_every_bench_layer_geometry():
             if bad or tuple(out.shape) != tuple(ref.shape):
                 failures.append((tag, bad))
             del out, gx, gw, gb, rx, rw, rb, ref, pre, gout
+            # ---- the same geometry as the step runs it (dvf/conv.py::ReluTag): inputs are outputs of ReLU layers, so the
+            # dgrad leaves multiplied by (x > 0); a ReLU layer itself receives dL/dpre (its consumers masked it) and its
+            # bias gradient is the extra column of the weight-gradient kernel (dvf_conv2d_wgrad_bias)
+            xs2 = [F.relu(x) for x in xs]
+            rx = [x.clone().requires_grad_(ng) for x, ng in zip(xs2, need_in)]
+            rw, rb = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            xin = torch.cat(rx, 1)
+            if transposed:
+                pre = F.conv_transpose2d(xin, rw, rb, stride=stride, padding=pad, output_padding=opad)
+            else:
+                pre = F.conv2d(xin, rw, rb, stride=stride, padding=pad)
+            if out_hw is not None:
+                pre = pre[:, :, :out_hw[0], :out_hw[1]]
+            ref = _ref_act(pre, act, alpha, beta)
+            gout = torch.randn(ref.shape, generator=gen)
+            if act == 1:
+                gout = gout * (pre.detach().abs() > 1e-4)
+            (ref * gout).sum().backward()
+            gx = [x.clone().to(DEV).requires_grad_(ng) for x, ng in zip(xs2, need_in)]
+            for x in gx:
+                x._dvf_relu_tag = ReluTag()
+            gw, gb = wt.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+            out = ConvFn.apply(gw, gb, tuple(cfg) + ((ReluTag(),) if act == 1 else ()), *gx)
+            go = gout * (ref.detach() > 0) if act == 1 else gout        # what masking consumers deliver
+            out.backward(go.to(DEV))
+            errs = {"fused wgrad": rel_err(gw.grad, rw.grad), "fused bias": rel_err(gb.grad, rb.grad)}
+            for i, (a, r, x0) in enumerate(zip(gx, rx, xs2)):
+                if r.grad is not None:
+                    errs[f"masked dgrad{i}"] = rel_err(a.grad, r.grad * (x0 > 0))
+            bad = {kk: v for kk, v in errs.items() if not v < TOL}
+            if bad:
+                failures.append((tag, bad))
+            del out, gx, gw, gb, rx, rw, rb, ref, pre, gout, go
     finally:
         STATE["layer_plans"] = L.PLAN_LOG
         L.PLAN_LOG = None

@@ -144,3 +144,71 @@ def test_small_ops():
         assert rel_err(C.area_downsample(img.to(DEV), (32 // s, 64 // s)), F.interpolate(img, (32 // s, 64 // s), mode="area")) < 1e-6
     assert rel_err(C.area_downsample(img.to(DEV), (10, 21)), F.interpolate(img, (10, 21), mode="area")) < 1e-6
     assert rel_err(C.bilinear_half(img.to(DEV)), F.interpolate(img, scale_factor=0.5, mode="bilinear")) < 1e-6
+
+
+FUSE_CASES = [
+    # name, cin, cmid, (N,H,W): a ReLU layer A (fuse_bwd) feeding three consumers
+    ("fuse_shallow", 16, 64, (2, 20, 36)),       # pipelined dgrad epilogue + stride-2 classes + head kernel post-pass
+    ("fuse_deep_splitk", 256, 512, (2, 4, 13)),  # split-K finish with the mask, transposed consumer
+    ("fuse_thin", 8, 16, (1, 33, 50)),           # unpacked kernels -> mask pass after them, odd sizes
+]
+
+
+@pytest.mark.parametrize("case", FUSE_CASES, ids=[c[0] for c in FUSE_CASES])
+def test_fused_relu_backward(case):
+    """ReLU backward + bias gradient of a producing layer done by its consumers' dgrad kernels (dvf_conv2d_dgrad_masked):
+    y = relu(convA(x)) feeds a 3x3 conv, a stride-2 conv / transposed conv and a 1-channel head; every gradient is
+    compared with torch CPU, and with the unfused path (FUSE_RELU_BWD = False) of this library."""
+    from dvf import conv as C
+    from dvf import lib as L
+    name, cin, cmid, (n, h, w) = case
+    gen = torch.Generator().manual_seed(321 + cin)
+    x = torch.randn(n, cin, h, w, generator=gen)
+
+    def build(fuse):
+        g2 = torch.Generator().manual_seed(99)
+        A = C.FusedConv2d(cin, cmid, 3, 1, 1, L.ACT_RELU, fuse_bwd=fuse)
+        B = C.FusedConv2d(cmid, 64, 3, 1, 1, L.ACT_RELU)
+        Cc = C.FusedConvTranspose2d(cmid, 32, 3, 2, 1, L.ACT_RELU, output_padding=1) if cmid >= 256 else \
+            C.FusedConv2d(cmid, 32, 3, 2, 1, L.ACT_RELU)
+        D = C.FusedConv2d(cmid, 1, 3, 1, 1, L.ACT_SIGMOID_AFFINE, alpha=10.0, beta=0.01)
+        mods = [A, B, Cc, D]
+        for m in mods:
+            with torch.no_grad():
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g2) / (m.weight[0].numel()) ** 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g2) * 0.1)
+        return mods
+
+    def run(mods, dev, functional):
+        A, B, Cc, D = mods
+        xi = x.clone().to(dev).requires_grad_(True)
+        if functional:        # torch reference on CPU
+            y = F.relu(F.conv2d(xi, A.weight, A.bias, padding=1))
+            o1 = F.relu(F.conv2d(y, B.weight, B.bias, padding=1))
+            if Cc.transposed:
+                o2 = F.relu(F.conv_transpose2d(y, Cc.weight, Cc.bias, stride=2, padding=1, output_padding=1))
+            else:
+                o2 = F.relu(F.conv2d(y, Cc.weight, Cc.bias, stride=2, padding=1))
+            o3 = 10.0 * torch.sigmoid(F.conv2d(y, D.weight, D.bias, padding=1)) + 0.01
+        else:
+            y = A(xi)
+            o1, o2, o3 = B(y), Cc(y), D(y)
+        gg = torch.Generator().manual_seed(5)
+        loss = sum((o * torch.randn(o.shape, generator=gg).to(dev)).sum() for o in (o1, o2, o3))
+        loss.backward()
+        grads = [xi.grad] + [p.grad for m in mods for p in (m.weight, m.bias)]
+        return [g.detach().cpu() for g in grads]
+
+    ref = run(build(False), "cpu", True)
+    fused_mods = [m.to(DEV) for m in build(True)]
+    got = run(fused_mods, DEV, False)
+    assert getattr(fused_mods[0], "fuse_bwd") is True
+    C.FUSE_RELU_BWD = False
+    try:
+        plain = run([m.to(DEV) for m in build(True)], DEV, False)
+    finally:
+        C.FUSE_RELU_BWD = True
+    names = ["x"] + [f"{m}.{p}" for m in "ABCD" for p in ("weight", "bias")]
+    for nm, r, g, pl in zip(names, ref, got, plain):
+        assert rel_err(g, r) < TOL, (name, nm, "fused vs torch", rel_err(g, r))
+        assert rel_err(pl, r) < TOL, (name, nm, "unfused vs torch", rel_err(pl, r))
