@@ -24,9 +24,17 @@ def _side_by_side(aux_fn, main_fn):
     cur = torch.cuda.current_stream()
     aux = L.aux_stream(cur.device)
     aux.wait_stream(cur)
-    with torch.cuda.stream(aux):
-        a_out = aux_fn()
-    m_out = main_fn()
+    # Host order: the depth network first, the pose network LAST.  Autograd runs ready nodes latest-created first, so the
+    # pose network's whole backward pass is enqueued (on its own stream) before the depth network's and overlaps it from
+    # the start; the other order leaves it -- and its weight gradients, Adam and repack -- as a serial tail of the step.
+    if os.environ.get("DVF_POSE_FIRST", "0") == "1":      # (the round-1 order, for A/B runs)
+        with torch.cuda.stream(aux):
+            a_out = aux_fn()
+        m_out = main_fn()
+    else:
+        m_out = main_fn()
+        with torch.cuda.stream(aux):
+            a_out = aux_fn()
     cur.wait_stream(aux)
 
     def _mark(t):

@@ -7,7 +7,7 @@ import csv, glob, collections
 rows = []
 for f in glob.glob("/tmp/tl/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"] + " #g%sx%sx%s/s%s" % (int(r.get("Grid_Size_X",0))//max(int(r.get("Workgroup_Size_X",1)),1), r.get("Grid_Size_Y","?"), r.get("Grid_Size_Z","?"), r.get("Stream_Id", "?"))))
 rows.sort()
 import re
 def short(n):
@@ -43,8 +43,8 @@ big = max(range(len(q1) - 1), key=lambda i: q1[i+1][0] - q1[i][1])
 g0, g1 = q1[big][1], q1[big+1][0]
 print("kernels around the largest main-queue gap (%.3f .. %.3f ms):" % ((g0 - t0) / 1e6, (g1 - t0) / 1e6))
 for s_, e_, q_, n in sel:
-    if e_ > g0 - 150000 and s_ < g1 + 50000:
-        print("   q%s  %.3f .. %.3f  (%.1f us)  %s" % (q_, (s_ - t0) / 1e6, (e_ - t0) / 1e6, (e_ - s_) / 1e3, short(n)))
+    if e_ > g0 - 150000 and s_ < g1 + 400000:
+        print("   q%s  %.3f .. %.3f  (%.1f us)  %s %s" % (q_, (s_ - t0) / 1e6, (e_ - t0) / 1e6, (e_ - s_) / 1e3, short(n), n[n.rfind("#"):]))
 # union busy time over all queues
 ev = sorted([(s, 1) for s, e, _, _ in sel] + [(e, -1) for s, e, _, _ in sel])
 cur = 0; last = None; idle = 0; conc = collections.Counter()
