@@ -120,7 +120,7 @@ def pmc_traffic(kernel):
     try:
         with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             ks = json.load(f)["kernels"]
-        names = {"conv_fwd_dgrad": ["conv_pipe", "conv_gather"]}.get(kernel, [kernel])
+        names = {"conv_fwd_dgrad": ["conv_pipe", "conv_gather"], "conv_wgrad": ["wgrad_pipe", "conv_wgrad"]}.get(kernel, [kernel])
         ks = [ks[n] for n in names if n in ks]
         if not ks:
             return None
@@ -129,7 +129,7 @@ def pmc_traffic(kernel):
         return None
 
 
-TRAFFIC_FILE = "r02_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_traffic.json")) else "r01_traffic.json"
+TRAFFIC_FILE = next((f for f in ("r02b_traffic.json", "r02_traffic.json", "r01_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r01_traffic.json")
 
 
 def measure_kernels(step):
@@ -388,7 +388,7 @@ def main():
         w = ks.get("conv_wgrad", {})
         if w.get("ms", 0) > 0:
             a = w["flops"] / (w["ms"] * 1e-3) / 1e12
-            result["roofline_wgrad"] = {"kernel": "conv_wgrad_kernel", "bound": "mfma", "achieved": a,
+            result["roofline_wgrad"] = {"kernel": "wgrad_pipe_kernel (+ head_wgrad_kernel for the 1-2 channel heads)", "bound": "mfma", "achieved": a,
                                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": a / PEAK_FP32_MFMA_TFLOPS,
                                         "traffic": pmc_traffic("conv_wgrad") if quoted else None, "calls_per_step": w["calls"],
                                         "ms_per_step": w["ms"]}

@@ -4,7 +4,7 @@ usage: traffic.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> <steps t
 "auto" counts the optimizer steps in the trace itself (adam_prep_kernel runs once per step, warm-up steps included)."""
 import collections, csv, glob, json, os, re, sys
 
-GROUPS = ["conv_pipe", "conv_gather", "conv_wgrad", "conv_pack_batch", "splitk_reduce", "act_bwd", "bias_act", "photo_fwd",
+GROUPS = ["conv_pipe", "conv_gather", "wgrad_pipe", "conv_wgrad", "conv_pack_batch", "splitk_reduce", "act_bwd", "bias_act", "photo_fwd",
           "photo_bwd", "smooth_fwd", "smooth_bwd", "adam", "fillBuffer"]
 
 
