@@ -274,32 +274,66 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
             }
         }
     }
-    // ---- epilogue: D[row = channel][col = pixel]; lanes 0-31 / 32-63 hold channel rows +0 / +4
+    // ---- epilogue: D[row = channel][col = pixel]; lanes 0-31 / 32-63 hold channel rows +0 / +4.  Output mode, activation
+    // and "every channel of the block exists" are launch constants: one store loop per combination (per element they cost
+    // a chain of scalar branches, an inlined sigmoid, three 64-bit multiplies and a dependent bias load each).
+    const int64_t HWo = (int64_t)a.OH * a.OW;
+    const bool full_m = m0 + 32 * MT <= a.M;
+    auto store_all = [&](auto modec, auto actc, auto fullc) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(modec)::value, ACT = decltype(actc)::value;
+        constexpr bool FULL = decltype(fullc)::value;
+        float bv[MT][16];
+        if constexpr (MODE == 0) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int oy = oy0 + opy[i], ox = ox0 + opx[i];
-        const int Y = oy * a.OS + c.py, X = ox * a.OS + c.px;
-        const bool pok = (oy < c.OHc) && (ox < c.OWc) && (Y < a.OH) && (X < a.OW);
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+                for (int r = 0; r < 16; ++r) {
+                    const int mm = m0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    bv[m][r] = (a.bias && mm < a.M) ? a.bias[mm] : 0.f;        // (all loads in flight together)
+                }
+        }
+        float *obase = a.out + (MODE == 2 ? (int64_t)ks * a.ws_slice : 0) + ((int64_t)n * a.M + m0 + 4 * kh) * HWo;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int mm = m0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (pok && mm < a.M) {
-                    float *op = a.out + (((int64_t)n * a.M + mm) * a.OH + Y) * a.OW + X;
-                    float v = acc[m][i][r];
-                    if (!a.atomic_out) {
-                        if (a.bias) v += a.bias[mm];
-                        *op = apply_act(v, a.act, a.alpha, a.beta);
-                    } else if (a.atomic_out == 2) {
-                        op[(int64_t)ks * a.ws_slice] = v;
-                    } else {
-                        atomicAdd(op, v);
+        for (int i = 0; i < NT; ++i) {
+            const int oy = oy0 + opy[i], ox = ox0 + opx[i];
+            const int Y = oy * a.OS + c.py, X = ox * a.OS + c.px;
+            const bool pok = (oy < c.OHc) && (ox < c.OWc) && (Y < a.OH) && (X < a.OW);
+            float *pbase = obase + (int64_t)Y * a.OW + X;
+            if (pok) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = m * 32 + (r & 3) + 8 * (r >> 2);
+                        if (FULL || m0 + 4 * kh + ml < a.M) {
+                            float *op = pbase + (int64_t)ml * HWo;          // (ml * HWo: scalar)
+                            const float v = acc[m][i][r];
+                            if constexpr (MODE == 0) {
+                                const float t = v + bv[m][r];
+                                if constexpr (ACT == DVF_ACT_RELU) *op = fmaxf(t, 0.f);
+                                else if constexpr (ACT == DVF_ACT_SIGMOID_AFFINE) *op = a.alpha * (1.f / (1.f + expf(-t))) + a.beta;
+                                else *op = t;
+                            } else if constexpr (MODE == 1) {
+                                atomicAdd(op, v);
+                            } else {
+                                *op = v;
+                            }
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    using std::integral_constant;
+    auto by_full = [&](auto modec, auto actc) __attribute__((always_inline)) {
+        if (full_m) store_all(modec, actc, std::true_type{});
+        else store_all(modec, actc, std::false_type{});
+    };
+    if (a.atomic_out == 2) by_full(integral_constant<int, 2>{}, integral_constant<int, DVF_ACT_NONE>{});
+    else if (a.atomic_out == 1) by_full(integral_constant<int, 1>{}, integral_constant<int, DVF_ACT_NONE>{});
+    else if (a.act == DVF_ACT_RELU) by_full(integral_constant<int, 0>{}, integral_constant<int, DVF_ACT_RELU>{});
+    else if (a.act == DVF_ACT_SIGMOID_AFFINE) by_full(integral_constant<int, 0>{}, integral_constant<int, DVF_ACT_SIGMOID_AFFINE>{});
+    else by_full(integral_constant<int, 0>{}, integral_constant<int, DVF_ACT_NONE>{});
 }
 
 // y = act(y + bias[c]) in place: finishes a split-K convolution.
@@ -1073,6 +1107,7 @@ int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qseg
     w.RSq = roundup(w.XA + (WGP_BW - 1) * o.S + o.KW - o.pad, 4);
     w.PHq = (WGP_BH - 1) * o.S + o.KH;
     w.x4 = (o.GW % 4 == 0 && o.QW % 4 == 0 && (align & 15) == 0) ? 1 : 0;
+    if (const char *e = dvf_tune("DVF_WG_X4")) w.x4 = w.x4 && atoi(e) != 0;      // tuning knob: 0 = 4-byte DMA lanes everywhere
     const int piece = w.x4 ? 256 : 64;
     w.NPIq = cdiv(w.PHq * w.RSq, piece);
     if (w.NPIq > WGP_MAXQ) return DVF_ERR_UNSUPPORTED;

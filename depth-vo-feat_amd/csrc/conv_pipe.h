@@ -435,37 +435,61 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
         }
         return;
     }
-    float bv[MT][16];
+    // The output mode, the activation and "every channel of this wave exists" are launch constants: the store loops are
+    // instantiated per combination (evaluating them per element cost 30+ scalar branches and an inlined sigmoid in every
+    // one of the 16*MT*NT stores of a lane -- microseconds per block), rows are reached by scalar multiples of HW.
+    const bool full_m = m0 + 32 * MT <= a.M;
+    auto store_all = [&](auto modec, auto actc, auto fullc) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(modec)::value, ACT = decltype(actc)::value;
+        constexpr bool FULL = decltype(fullc)::value;
+        float bv[MT][16];
+        if constexpr (MODE == 0) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bv[m][r] = bias_lds[wm * (32 * MT) + 4 * kh + m * 32 + (r & 3) + 8 * (r >> 2)];
+                for (int r = 0; r < 16; ++r) bv[m][r] = bias_lds[wm * (32 * MT) + 4 * kh + m * 32 + (r & 3) + 8 * (r >> 2)];
+        }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int oy = oy0 + opy[i], ox = ox0 + opx[i], n = n0 + opn[i];
-        const int Y = oy * a.OS + c.py, X = ox * a.OS + c.px;
-        const bool pok = (oy < c.OHc) && (ox < c.OWc) && (Y < a.OH) && (X < a.OW) && (opn[i] < a.BN) && (n < a.N);
-        float *pbase = outp + ((int64_t)n * a.M + m0 + 4 * kh) * HW + (int64_t)Y * a.OW + X;
+        for (int i = 0; i < NT; ++i) {
+            const int oy = oy0 + opy[i], ox = ox0 + opx[i], n = n0 + opn[i];
+            const int Y = oy * a.OS + c.py, X = ox * a.OS + c.px;
+            const bool pok = (oy < c.OHc) && (ox < c.OWc) && (Y < a.OH) && (X < a.OW) && (opn[i] < a.BN) && (n < a.N);
+            float *pbase = outp + ((int64_t)n * a.M + m0 + 4 * kh) * HW + (int64_t)Y * a.OW + X;
+            if (pok) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+                for (int m = 0; m < MT; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = m * 32 + (r & 3) + 8 * (r >> 2);
-                const int mm = m0 + 4 * kh + ml;
-                if (pok && mm < a.M) {
-                    float *op = pbase + (int64_t)ml * HW;
-                    float v = acc[m][i][r];
-                    if (a.out_mode == 0) {
-                        *op = apply_act(v + bv[m][r], a.act, a.alpha, a.beta);
-                    } else if (a.out_mode == 1) {
-                        atomicAdd(op, v);
-                    } else {
-                        *op = v;
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = m * 32 + (r & 3) + 8 * (r >> 2);
+                        if (FULL || m0 + 4 * kh + ml < a.M) {
+                            float *op = pbase + (int64_t)ml * HW;      // (ml * HW: scalar)
+                            const float v = acc[m][i][r];
+                            if constexpr (MODE == 0) {
+                                const float t = v + bv[m][r];
+                                if constexpr (ACT == DVF_ACT_RELU) *op = fmaxf(t, 0.f);
+                                else if constexpr (ACT == DVF_ACT_SIGMOID_AFFINE) *op = a.alpha * (1.f / (1.f + expf(-t))) + a.beta;
+                                else *op = t;
+                            } else if constexpr (MODE == 1) {
+                                atomicAdd(op, v);
+                            } else {
+                                *op = v;
+                            }
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    using std::integral_constant;
+    auto by_full = [&](auto modec, auto actc) __attribute__((always_inline)) {
+        if (full_m) store_all(modec, actc, std::true_type{});
+        else store_all(modec, actc, std::false_type{});
+    };
+    if (a.out_mode == 2) by_full(integral_constant<int, 2>{}, integral_constant<int, DVF_ACT_NONE>{});
+    else if (a.out_mode == 1) by_full(integral_constant<int, 1>{}, integral_constant<int, DVF_ACT_NONE>{});
+    else if (a.act == DVF_ACT_RELU) by_full(integral_constant<int, 0>{}, integral_constant<int, DVF_ACT_RELU>{});
+    else if (a.act == DVF_ACT_SIGMOID_AFFINE) by_full(integral_constant<int, 0>{}, integral_constant<int, DVF_ACT_SIGMOID_AFFINE>{});
+    else by_full(integral_constant<int, 0>{}, integral_constant<int, DVF_ACT_NONE>{});
 }
 
 // Launch one (MT, NT, WM) family; CKH in {2,4,8} and TBU in {2,3,4} are dispatched inside.  Defined in the

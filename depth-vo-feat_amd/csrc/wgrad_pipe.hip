@@ -40,6 +40,7 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
     const int w0 = (int)(((int64_t)a.W * b) / nb), w1 = (int)(((int64_t)a.W * (b + 1)) / nb);
     const int nitems = w1 - w0;
     if (nitems <= 0) return;
+    if (DVF_DBG(a, 32)) return;            // (ablation: dispatch only)
     int mc = w0 / a.ntiles;                // output block: m-block = mc % mtiles, channel chunk = mc / mtiles
     int tile = w0 - mc * a.ntiles;
 
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
             }
             if (tile == a.ntiles) { tile = 0; n = 0; ++mc; }
         };
+        if (DVF_DBG(a, 64)) return;        // (ablation: dispatch + prologue)
         // item x lives in stage x & 1 and is issued one item ahead
         issue(0);
         advance();
@@ -252,23 +254,38 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
         const int mb = mcv % a.mtiles, cb = mcv / a.mtiles;
         const int m0 = mb * MB, c0 = cb * a.CK;
         const int nch = min(a.CK, a.Cq - c0);
+        const bool full_m = m0 + MB <= a.M;                       // every row of the block exists: no per-element test
 #pragma unroll
         for (int u = 0; u < NTW; ++u) {
-            const bool colok = cjv[u] >= 0 && cjv[u] < nch;
-            const bool biascol = cjv[u] == -2 && cb == 0;          // (every chunk computes it; chunk 0 delivers it)
-            const int64_t gcol = (int64_t)(a.g_cbase + c0 + cjv[u]) * a.KK + tjv[u];
+            const bool colok = cjv[u] >= 0 && cjv[u] < nch && !DVF_DBG(a, 8);
+            // per-lane part of the address once; the row (m, r) adds a SCALAR multiple of the row stride
+            float *gl = a.G + (int64_t)(a.g_mbase + m0 + 4 * kh) * a.g_mstride + (int64_t)(a.g_cbase + c0 + cjv[u]) * a.KK + tjv[u];
+            if (colok) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = m * 32 + (r & 3) + 8 * (r >> 2);
+                        if (full_m || m0 + 4 * kh + ml < a.M) atomicAdd(gl + (int64_t)ml * a.g_mstride, acc[m][u][r]);
+                    }
+            }
+            if (cjv[u] == -2 && cb == 0) {                         // bias column (every chunk computes it; chunk 0 delivers it)
+                float *bl = a.dbias + m0 + 4 * kh;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = m * 32 + (r & 3) + 8 * (r >> 2);
+                        if (full_m || m0 + 4 * kh + ml < a.M) atomicAdd(bl + ml, acc[m][u][r]);
+                    }
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int mm = m0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (colok && mm < a.M && !DVF_DBG(a, 8))
-                        atomicAdd(a.G + (int64_t)(a.g_mbase + mm) * a.g_mstride + gcol, acc[m][u][r]);
-                    if (biascol && mm < a.M) atomicAdd(a.dbias + mm, acc[m][u][r]);
-                    acc[m][u][r] = 0.f;
-                }
+                for (int r = 0; r < 16; ++r) acc[m][u][r] = 0.f;
         }
     };
+    if (DVF_DBG(a, 64)) return;
     for (int x = 0; x < nitems; ++x) {
         // item x has landed (its producers waited for it) and item x-1 is fully consumed.  No vmcnt wait here: the
         // atomics of a flush stay in flight across the barrier.
@@ -276,7 +293,7 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
         if (!DVF_DBG(a, 4)) consume(x & 1);
         int mc_next = mc;
         if (++tile == a.ntiles) { tile = 0; ++mc_next; }
-        if (x == nitems - 1 || mc_next != mc) flush(mc);
+        if ((x == nitems - 1 || mc_next != mc) && !DVF_DBG(a, 128)) flush(mc);
         mc = mc_next;
     }
 }
