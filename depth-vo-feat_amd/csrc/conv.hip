@@ -53,6 +53,8 @@ struct GatherArgs {
     int lsw, lsh, TGX, BW, BH, tilesX, tilesY;
     int PSmax, Tmax, WD; // LDS carve: patch CK*PSmax | weights Tmax*CK*COTP | wdec WD | tapB Tmax | inv 64
     int tapmap[52];      // class c uses tapmap[cls[c].tap0 + t]: class tap -> tap index of the stored kernel
+    const float *mask;   // (dgrad, atomic_out 0) ReLU backward of the producing layer: out = (mask > 0) ? v : 0; same shape as out
+    int *mask_done;      // host side: set to 1 when the launch applied the mask itself
 };
 
 // MT x 32 output channels, 4*NT tiles of 32 pixels per block, CK = 2*CKH reduction channels per LDS chunk.
@@ -299,6 +301,17 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
             const int Y = oy * a.OS + c.py, X = ox * a.OS + c.px;
             const bool pok = (oy < c.OHc) && (ox < c.OWc) && (Y < a.OH) && (X < a.OW);
             float *pbase = obase + (int64_t)Y * a.OW + X;
+            float mk[MT][16];
+            if constexpr (MODE == 3) {           // all mask loads of the tile first (invalid elements read element 0)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = m * 32 + (r & 3) + 8 * (r >> 2);
+                        const bool ok = pok && (FULL || m0 + 4 * kh + ml < a.M);
+                        mk[m][r] = a.mask[ok ? (pbase - a.out) + (int64_t)ml * HWo : 0];
+                    }
+            }
             if (pok) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
@@ -308,7 +321,9 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
                         if (FULL || m0 + 4 * kh + ml < a.M) {
                             float *op = pbase + (int64_t)ml * HWo;          // (ml * HWo: scalar)
                             const float v = acc[m][i][r];
-                            if constexpr (MODE == 0) {
+                            if constexpr (MODE == 3) {                   // dgrad + ReLU backward of the producing layer
+                                *op = mk[m][r] > 0.f ? v : 0.f;
+                            } else if constexpr (MODE == 0) {
                                 const float t = v + bv[m][r];
                                 if constexpr (ACT == DVF_ACT_RELU) *op = fmaxf(t, 0.f);
                                 else if constexpr (ACT == DVF_ACT_SIGMOID_AFFINE) *op = a.alpha * (1.f / (1.f + expf(-t))) + a.beta;
@@ -329,7 +344,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const GatherArgs a) {
         if (full_m) store_all(modec, actc, std::true_type{});
         else store_all(modec, actc, std::false_type{});
     };
-    if (a.atomic_out == 2) by_full(integral_constant<int, 2>{}, integral_constant<int, DVF_ACT_NONE>{});
+    if (a.atomic_out == 0 && a.mask) by_full(integral_constant<int, 3>{}, integral_constant<int, DVF_ACT_NONE>{});
+    else if (a.atomic_out == 2) by_full(integral_constant<int, 2>{}, integral_constant<int, DVF_ACT_NONE>{});
     else if (a.atomic_out == 1) by_full(integral_constant<int, 1>{}, integral_constant<int, DVF_ACT_NONE>{});
     else if (a.act == DVF_ACT_RELU) by_full(integral_constant<int, 0>{}, integral_constant<int, DVF_ACT_RELU>{});
     else if (a.act == DVF_ACT_SIGMOID_AFFINE) by_full(integral_constant<int, 0>{}, integral_constant<int, DVF_ACT_SIGMOID_AFFINE>{});
@@ -862,6 +878,8 @@ int run_classes(const GatherArgs &base, const ClassSpec *cls, int ncls, bool cov
         if (split && hipMemsetAsync(a.out, 0, sizeof(float) * total, st) != hipSuccess) return DVF_ERR_LAUNCH;
         a.atomic_out = split ? 1 : 0;
     }
+    if (a.atomic_out != 0) a.mask = nullptr;               // (the caller runs the mask pass over the finished sums)
+    else if (a.mask && a.mask_done) *a.mask_done = 1;
     if (pl.MT == 2 && pl.NT == 2) rc = launch_gather_ck<2, 2>(a, pl, st);
     else if (pl.MT == 2) rc = launch_gather_ck<2, 1>(a, pl, st);
     else if (pl.NT == 2) rc = launch_gather_ck<1, 2>(a, pl, st);
@@ -1049,12 +1067,14 @@ int dvf_conv2d_fwd(const dvf_conv_desc *d, const float *const *in_segs, const in
 namespace {
 // dgrad of one input segment with the unpacked weights: the head kernel for narrow segments, else conv_gather_kernel
 int dgrad_segment_unpacked(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int off, int segc,
-                           hipStream_t st, float *ws = nullptr, int64_t ws_floats = 0, int64_t *ws_need = nullptr) {
+                           hipStream_t st, float *ws = nullptr, int64_t ws_floats = 0, int64_t *ws_need = nullptr,
+                           const float *mask = nullptr, int *mask_done = nullptr) {
     if (ws_need) *ws_need = 0;
     if (dvf_head_seg_dgrad_applicable(d, segc)) return ws_need ? DVF_OK : dvf_head_seg_dgrad(d, dpre, w, din, off, segc, st);
     GatherArgs a{};
     a.in[0] = dpre; a.segC[0] = d->C_out; a.nseg = 1;
     a.w = w; a.KK = d->KH * d->KW; a.m_base = off; a.M = segc; a.bias = nullptr; a.out = din;
+    a.mask = mask; a.mask_done = mask_done;
     a.Mtot = d->C_in; a.Rtot = d->C_out;
     a.N = d->N; a.IH = d->H_out; a.IW = d->W_out; a.OH = d->H_in; a.OW = d->W_in;
     a.act = DVF_ACT_NONE;
@@ -1487,9 +1507,11 @@ static int dgrad_all(const dvf_conv_desc *d, const float *dpre, const float *pac
         if (rc == DVF_ERR_UNSUPPORTED) {                                      // narrow segment: unpacked kernels
             if (din_segs[s]) {
                 if (!w) return DVF_ERR_INVALID_ARG;
-                rc = dgrad_segment_unpacked(d, dpre, w, din_segs[s], off, seg_channels[s], st, ws, ws_floats);
+                int done = 0;
+                rc = dgrad_segment_unpacked(d, dpre, w, din_segs[s], off, seg_channels[s], st, ws, ws_floats, nullptr,
+                                            mask_segs ? mask_segs[s] : nullptr, &done);
                 if (rc) return rc;
-                rc = postpass(s);
+                if (!done) rc = postpass(s);
                 if (rc) return rc;
             }
         } else {
