@@ -1023,6 +1023,11 @@ int fwd_unpacked(const dvf_conv_desc *d, const float *const *in_segs, const int 
             if (!in_segs[s]) return DVF_ERR_INVALID_ARG;
         return dvf_head_fwd_segs(d, in_segs, seg_channels, nseg, w, bias, out, dvf_stream(stream));
     }
+    if (dvf_dconvt_applicable(d, nseg)) {                  // thin stride-2 transposed convolutions: direct kernel
+        if (ws_need) return DVF_OK;
+        if (!in_segs[0]) return DVF_ERR_INVALID_ARG;
+        return dvf_dconvt_fwd(d, in_segs[0], w, bias, out, dvf_stream(stream));
+    }
     GatherArgs a{};
     for (int s = 0; s < nseg; ++s) {
         if (!ws_need && !in_segs[s]) return DVF_ERR_INVALID_ARG;
@@ -1386,6 +1391,7 @@ int64_t pipe_sizes(const dvf_conv_desc *d, const int *seg_channels, int nseg, in
     PipeOp op;
     int64_t total = 0, nf = 0, wf = 0, wmax = 0;
     int nsup = 0;
+    if (op_kind == 0 && !want_ws && dvf_dconvt_applicable(d, nseg)) return DVF_ERR_UNSUPPORTED;   // (forward runs the direct kernel)
     if (op_kind == 0) {
         rc = make_fwd_op(d, nullptr, seg_channels, nseg, nullptr, nullptr, op);
         if (rc) return rc;

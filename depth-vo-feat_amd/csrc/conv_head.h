@@ -11,3 +11,6 @@ int dvf_head_wgrad(const dvf_conv_desc *d, const float *in, const float *dpre, f
 bool dvf_head_seg_dgrad_applicable(const dvf_conv_desc *d, int segc);
 int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int seg_off, int segc,
                        hipStream_t st);
+// direct forward of the thin stride-2 transposed convolutions (3x3 / 4x4, 16 or 32 output channels)
+bool dvf_dconvt_applicable(const dvf_conv_desc *d, int nseg);
+int dvf_dconvt_fwd(const dvf_conv_desc *d, const float *in, const float *w, const float *bias, float *out, hipStream_t st);

@@ -212,6 +212,94 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float *__restrict
     }
 }
 
+
+// ------------------------------------------------------------------------------------ thin stride-2 transposed convolutions
+// ConvTranspose2d(k = 3, s = 2, p = 1, output_padding = 1) and (k = 4, s = 2, p = 1) with 16 output channels
+// (DispNetS upconv1, DispNetS.py:62-64; PoseExpNet upconv1, PoseExpNet_sfm.py:38-41): the output is at or
+// near the input resolution of the network, the reduction is 32-64 channels x 1-4 taps per output pixel.  As an MFMA GEMM
+// that is four parity-class launches-in-one with 16 of 32 rows empty and a 32-256 deep K: the gather kernel ran them at
+// 10-15 % of the matrix peak.  Direct form: one thread owns ONE INPUT pixel and its 2x2 output pixels x CO channels
+// (4*CO accumulators); per input channel it reads the 2x2 (k = 3) or 3x3 (k = 4) input neighbourhood and does the
+// 9*CO (16*CO) FMAs of that channel.  The weights of the layer (C*CO*k*k floats, <= 64 KB) are copied to LDS once per block
+// and read back as uniform-address ds_read_b128 (broadcast: four weights per read, one read per four FMAs).  (Scalar loads
+// + SGPR operands were tried first: 6-23 TF, the waves sit in s_waitcnt behind the weight stream.)  Layout: w[ci][co][a][b].
+//   k = 3: out(2y+dy, 2x+dx) uses rows (a, iy) in {(1, y)} for dy = 0, {(0, y+1), (2, y)} for dy = 1      (Y = 2*iy - 1 + a)
+//   k = 4: rows {(1, y), (3, y-1)} for dy = 0, {(0, y+1), (2, y)} for dy = 1;  columns likewise.
+template <int CO, int K>
+__global__ __launch_bounds__(256) void dconvt_s2_fwd_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, float *__restrict__ out, int C, int H,
+                                                            int W, int OH, int OW, int act, float alpha, float beta) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];      // [C][CO*K*K]
+    constexpr int WPC = CO * K * K;
+    static_assert(WPC % 4 == 0, "weights of one input channel are read in 16-byte pieces");
+    typedef float f4w __attribute__((ext_vector_type(4)));
+    for (int e = threadIdx.x; e < C * WPC / 4; e += 256)
+        reinterpret_cast<f4w *>(wlds)[e] = reinterpret_cast<const f4w *>(w)[e];
+    __syncthreads();
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), n = blockIdx.z;
+    const bool inside = x < W && y < H;
+    // neighbourhood offsets: rows y-1, y, y+1 -> index 0, 1, 2 (k = 3 never uses index 0)
+    const bool rok[3] = {y - 1 >= 0 && y - 1 < H, y < H, y + 1 < H}, cok[3] = {x - 1 >= 0 && x - 1 < W, x < W, x + 1 < W};
+    float acc[2][2][CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        const float b = bias ? bias[co] : 0.f;
+        acc[0][0][co] = acc[0][1][co] = acc[1][0][co] = acc[1][1][co] = b;
+    }
+    const int64_t plane = (int64_t)H * W;
+    const float *ip = in + (int64_t)n * C * plane + (int64_t)y * W + x;
+    for (int ci = 0; ci < C; ++ci) {
+        float v[3][3];
+#pragma unroll
+        for (int r = (K == 3 ? 1 : 0); r < 3; ++r)
+#pragma unroll
+            for (int c = (K == 3 ? 1 : 0); c < 3; ++c) v[r][c] = (rok[r] && cok[c]) ? ip[(r - 1) * W + (c - 1)] : 0.f;
+        const f4w *wc = reinterpret_cast<const f4w *>(wlds + ci * WPC);     // uniform address: LDS broadcast
+        f4w wq[WPC / 4];
+#pragma unroll
+        for (int q = 0; q < WPC / 4; ++q) wq[q] = wc[q];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+#pragma unroll
+            for (int a = 0; a < K; ++a) {
+                // output row parity and input row of tap a
+                const int dy = (a + 1) & 1;                           // Y = 2*iy - 1 + a  ->  Y parity = (a + 1) & 1
+                const int ry = 1 + ((dy + 1 - a) >> 1);             // iy - y + 1 = 1 + (dy + 1 - a) / 2  (exact: even numerator)
+#pragma unroll
+                for (int b = 0; b < K; ++b) {
+                    const int dx = (b + 1) & 1;
+                    const int rx = 1 + ((dx + 1 - b) >> 1);
+                    const int f = co * K * K + a * K + b;
+                    acc[dy][dx][co] = fmaf(wq[f >> 2][f & 3], v[ry][rx], acc[dy][dx][co]);
+                }
+            }
+        }
+        ip += plane;
+    }
+    if (!inside) return;
+    const int64_t oplane = (int64_t)OH * OW;
+    float *op = out + (int64_t)n * CO * oplane;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        const int Y = 2 * y + dy;
+        if (Y >= OH) continue;
+        const int X = 2 * x;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            float r0 = head_act(acc[dy][0][co], act, alpha, beta), r1 = head_act(acc[dy][1][co], act, alpha, beta);
+            float *q = op + co * oplane + (int64_t)Y * OW + X;
+            if (X + 1 < OW && (OW & 1) == 0) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 t; t.x = r0; t.y = r1;
+                *reinterpret_cast<f2 *>(q) = t;                   // (X even, OW even: 8-byte aligned)
+            } else {
+                if (X < OW) q[0] = r0;
+                if (X + 1 < OW) q[1] = r1;
+            }
+        }
+    }
+}
+
 inline int cdivh(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
@@ -220,6 +308,27 @@ bool dvf_head_applicable(const dvf_conv_desc *d, int nseg) {
     return nseg == 1 && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->C_out >= 1 &&
            d->C_out <= 4 && d->H_out == d->H_in && d->W_out == d->W_in && d->C_in >= 4 && d->C_in * d->C_out <= 1024 &&
            dvf_tune("DVF_NO_HEAD") == nullptr;
+}
+
+bool dvf_dconvt_applicable(const dvf_conv_desc *d, int nseg) {
+    const bool k3 = d->KH == 3 && d->KW == 3, k4 = d->KH == 4 && d->KW == 4;
+    return nseg == 1 && d->transposed && d->stride == 2 && d->pad == 1 && (k3 || k4) && d->C_out == 16 &&
+           d->C_in >= 8 && d->C_in <= 64 && d->H_out <= 2 * d->H_in && d->W_out <= 2 * d->W_in &&
+           (int64_t)d->H_in * d->W_in >= 64 * 64 && (int64_t)d->N * d->C_out * d->H_out * d->W_out < ((int64_t)1 << 31) &&
+           dvf_tune("DVF_NO_DCONVT") == nullptr;
+}
+
+int dvf_dconvt_fwd(const dvf_conv_desc *d, const float *in, const float *w, const float *bias, float *out, hipStream_t st) {
+    const dim3 grid(cdivh(d->W_in, 64), cdivh(d->H_in, 4), d->N);
+    const size_t lds = (size_t)d->C_in * d->C_out * d->KH * d->KW * 4;
+    if ((reinterpret_cast<uintptr_t>(w) & 15) != 0 || lds > 64 * 1024) return DVF_ERR_UNSUPPORTED;
+#define DCONVT(CO, K) dconvt_s2_fwd_kernel<CO, K><<<grid, 256, lds, st>>>(in, w, bias, out, d->C_in, d->H_in, d->W_in, d->H_out, d->W_out, d->act, d->alpha, d->beta)
+    if (d->KH == 3) DCONVT(16, 3);
+    else DCONVT(16, 4);
+#undef DCONVT
+    DVF_LAUNCH_CHECK();
+    dvf_plan_note(DVF_K_DCONVT_FWD, d->C_out, d->KH);
+    return DVF_OK;
 }
 
 #define HEAD_DISPATCH(MOV, CALL)                 \

@@ -29,7 +29,7 @@ static inline const char *dvf_tune(const char *) { return nullptr; }
 // entry); dvf_conv2d_last_plans() reads it back.  Tests use it to prove that the plans exercised by the parity cases
 // are the plans the benchmark step runs.
 enum { DVF_K_PIPE = 1, DVF_K_GATHER = 2, DVF_K_HEAD_FWD = 3, DVF_K_HEAD_DGRAD = 4, DVF_K_HEAD_WGRAD = 5, DVF_K_WGRAD = 6,
-       DVF_K_HEAD_SEG_DGRAD = 7, DVF_K_WGRAD_PIPE = 8 };
+       DVF_K_HEAD_SEG_DGRAD = 7, DVF_K_WGRAD_PIPE = 8, DVF_K_DCONVT_FWD = 9 };
 constexpr int DVF_PLAN_INTS = 12, DVF_PLAN_MAX = 8;
 struct DvfPlanLog { int n; int rec[DVF_PLAN_MAX][DVF_PLAN_INTS]; };
 DvfPlanLog &dvf_plan_log();

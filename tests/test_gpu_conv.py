@@ -47,6 +47,11 @@ CASES = [
     ("thin16_concat2_ragged", [16, 1], 16, 3, 1, 1, 0, False, 1, (2, 70, 75), None),
     ("thin16_concat3", [8, 13, 3], 16, 3, 1, 1, 0, False, 1, (1, 64, 66), None),
     ("thin16_single_noact", [16], 16, 3, 1, 1, 0, False, 0, (1, 65, 64), None),
+    # thin stride-2 transposed convolutions (upconv1 / upconv2 of both networks): direct forward kernel
+    ("dconvt3_16", [32], 16, 3, 2, 1, 1, True, 1, (2, 64, 66), None),
+    ("dconvt3_16_crop", [64], 16, 3, 2, 1, 1, True, 1, (1, 64, 72), (127, 143)),
+    ("dconvt4_16", [32], 16, 4, 2, 1, 0, True, 1, (1, 64, 64), None),
+    ("dconvt4_16_crop_odd", [24], 16, 4, 2, 1, 0, True, 0, (1, 65, 70), (129, 139)),
 ]
 
 
