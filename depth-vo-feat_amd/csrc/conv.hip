@@ -1075,7 +1075,11 @@ int dgrad_segment_unpacked(const dvf_conv_desc *d, const float *dpre, const floa
                            hipStream_t st, float *ws = nullptr, int64_t ws_floats = 0, int64_t *ws_need = nullptr,
                            const float *mask = nullptr, int *mask_done = nullptr) {
     if (ws_need) *ws_need = 0;
-    if (dvf_head_seg_dgrad_applicable(d, segc)) return ws_need ? DVF_OK : dvf_head_seg_dgrad(d, dpre, w, din, off, segc, st);
+    if (dvf_head_seg_dgrad_applicable(d, segc)) {
+        if (ws_need) return DVF_OK;
+        if (mask && mask_done) *mask_done = 1;
+        return dvf_head_seg_dgrad(d, dpre, w, din, off, segc, st, mask);
+    }
     GatherArgs a{};
     a.in[0] = dpre; a.segC[0] = d->C_out; a.nseg = 1;
     a.w = w; a.KK = d->KH * d->KW; a.m_base = off; a.M = segc; a.bias = nullptr; a.out = din;

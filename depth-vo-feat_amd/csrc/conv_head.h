@@ -10,7 +10,7 @@ int dvf_head_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, fl
 int dvf_head_wgrad(const dvf_conv_desc *d, const float *in, const float *dpre, float *dw, int accumulate, hipStream_t st);
 bool dvf_head_seg_dgrad_applicable(const dvf_conv_desc *d, int segc);
 int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int seg_off, int segc,
-                       hipStream_t st);
+                       hipStream_t st, const float *mask = nullptr);     // mask: (mask > 0) ? din : 0 (ReLU backward of the segment's producer)
 // direct forward of the thin stride-2 transposed convolutions (3x3 / 4x4, 16 or 32 output channels)
 bool dvf_dconvt_applicable(const dvf_conv_desc *d, int nseg);
 int dvf_dconvt_fwd(const dvf_conv_desc *d, const float *in, const float *w, const float *bias, float *out, hipStream_t st);

@@ -42,7 +42,7 @@ template <int MO>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const float *__restrict__ w,
                                                        const float *__restrict__ bias, float *__restrict__ out, int C, int H,
                                                        int W, int tilesX, int act, float alpha, float beta, int ws_m, int ws_c,
-                                                       int flip) {
+                                                       int flip, const float *__restrict__ mask) {
     __shared__ float tile[HCK * FP_N];
     extern __shared__ float wsh[];           // [MO][C][9] weights of the block (tap order already flipped if asked)
     for (int e = threadIdx.x; e < MO * C * 9; e += 256) {
@@ -117,9 +117,17 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const 
     for (int r = 0; r < 2; ++r) {
         const int y = y0 + ly + r;
         if (y < H && x < W) {
+            if (mask) {        // (segment dgrad) ReLU backward of the layer that produced this segment: its output is the mask
 #pragma unroll
-            for (int m = 0; m < MO; ++m)
-                out[((int64_t)n * MO + m) * plane + (int64_t)y * W + x] = head_act(acc[r][m], act, alpha, beta);
+                for (int m = 0; m < MO; ++m) {
+                    const int64_t idx = ((int64_t)n * MO + m) * plane + (int64_t)y * W + x;
+                    out[idx] = mask[idx] > 0.f ? acc[r][m] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MO; ++m)
+                    out[((int64_t)n * MO + m) * plane + (int64_t)y * W + x] = head_act(acc[r][m], act, alpha, beta);
+            }
         }
     }
 }
@@ -371,7 +379,7 @@ int dvf_head_fwd_segs(const dvf_conv_desc *d, const float *const *in_segs, const
     for (int s = 0; s < HEAD_MAX_SEGS; ++s) { in.p[s] = s < nseg ? in_segs[s] : in_segs[0]; in.c[s] = s < nseg ? seg_channels[s] : 0; }
     in.n = nseg;
     HEAD_FWD_DISPATCH(d->C_out, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_in * 9 * 4, st>>>(
-                                    in, w, bias, out, d->C_in, d->H_in, d->W_in, tilesX, d->act, d->alpha, d->beta, d->C_in * 9, 9, 0)));
+                                    in, w, bias, out, d->C_in, d->H_in, d->W_in, tilesX, d->act, d->alpha, d->beta, d->C_in * 9, 9, 0, nullptr)));
     DVF_LAUNCH_CHECK();
     dvf_plan_note(DVF_K_HEAD_FWD, d->C_out, nseg);
     return DVF_OK;
@@ -389,7 +397,7 @@ bool dvf_head_seg_dgrad_applicable(const dvf_conv_desc *d, int segc) {
 }
 
 int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int seg_off, int segc,
-                       hipStream_t st) {
+                       hipStream_t st, const float *mask) {
     const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, FT_H);
     const dim3 grid(tilesX * tilesY, d->N);
     const float *wseg = w + (int64_t)seg_off * 9;
@@ -397,7 +405,7 @@ int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w
     for (int s = 0; s < HEAD_MAX_SEGS; ++s) { in.p[s] = dpre; in.c[s] = s == 0 ? d->C_out : 0; }
     in.n = 1;
     HEAD_FWD_DISPATCH(segc, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_out * 9 * 4, st>>>(
-                                in, wseg, nullptr, din, d->C_out, d->H_in, d->W_in, tilesX, DVF_ACT_NONE, 1.f, 0.f, 9, d->C_in * 9, 1)));
+                                in, wseg, nullptr, din, d->C_out, d->H_in, d->W_in, tilesX, DVF_ACT_NONE, 1.f, 0.f, 9, d->C_in * 9, 1, mask)));
     DVF_LAUNCH_CHECK();
     dvf_plan_note(DVF_K_HEAD_SEG_DGRAD, segc);
     return DVF_OK;
