@@ -44,10 +44,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const 
                                                        int W, int tilesX, int act, float alpha, float beta, int ws_m, int ws_c,
                                                        int flip, const float *__restrict__ mask) {
     __shared__ float tile[HCK * FP_N];
-    extern __shared__ float wsh[];           // [MO][C][9] weights of the block (tap order already flipped if asked)
+    extern __shared__ __attribute__((aligned(16))) float wsh[];           // [MO][C][9] weights of the block (tap order already flipped if asked)
+    // LDS layout: [m][c][9] for the 1-4 channel heads; [c][m][9] for the 16-channel variant, whose inner loop reads the 144
+    // weights of a channel as 36 uniform-address ds_read_b128 (one broadcast read per four FMAs pairs instead of one per pair)
     for (int e = threadIdx.x; e < MO * C * 9; e += 256) {
         const int m = e / (C * 9), r = e - m * (C * 9), c = r / 9, k = r - c * 9;
-        wsh[e] = w[(int64_t)m * ws_m + (int64_t)c * ws_c + (flip ? 8 - k : k)];
+        const float wv = w[(int64_t)m * ws_m + (int64_t)c * ws_c + (flip ? 8 - k : k)];
+        if (MO == 16) wsh[(c * MO + m) * 9 + k] = wv;
+        else wsh[e] = wv;
     }
     const int n = blockIdx.y, tY = blockIdx.x / tilesX, tX = blockIdx.x - tY * tilesX;
     const int y0 = tY * FT_H, x0 = tX * HT_W;
@@ -99,14 +103,31 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const 
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 3; ++b) v[a][b] = t[a * HP_W + b];
+            if constexpr (MO == 16) {
+                typedef float f4h __attribute__((ext_vector_type(4)));
+                const f4h *wq = reinterpret_cast<const f4h *>(wsh + (cg + ch) * (MO * 9));     // 16-byte aligned: 144 floats per channel
+                f4h wr[MO * 9 / 4];
 #pragma unroll
-            for (int m = 0; m < MO; ++m) {
-                const float *wm = wsh + (m * C + cg + ch) * 9;             // LDS broadcast reads
+                for (int q = 0; q < MO * 9 / 4; ++q) wr[q] = wq[q];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const float wk = wm[k];
-                    acc[0][m] = fmaf(wk, v[k / 3][k % 3], acc[0][m]);
-                    acc[1][m] = fmaf(wk, v[k / 3 + 1][k % 3], acc[1][m]);
+                for (int m = 0; m < MO; ++m)
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const int f = m * 9 + k;
+                        const float wk = wr[f >> 2][f & 3];
+                        acc[0][m] = fmaf(wk, v[k / 3][k % 3], acc[0][m]);
+                        acc[1][m] = fmaf(wk, v[k / 3 + 1][k % 3], acc[1][m]);
+                    }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MO; ++m) {
+                    const float *wm = wsh + (m * C + cg + ch) * 9;             // LDS broadcast reads
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const float wk = wm[k];
+                        acc[0][m] = fmaf(wk, v[k / 3][k % 3], acc[0][m]);
+                        acc[1][m] = fmaf(wk, v[k / 3 + 1][k % 3], acc[1][m]);
+                    }
                 }
             }
         }
