@@ -184,9 +184,8 @@ class FlatAdam:
             comm.wait_stream(self._main_stream)               # the stream zero_grad()/backward() were issued from
         for side in self._sides.values():
             comm.wait_stream(side)
-        for dev, aux in L.AUX_STREAMS.items():
-            if dev == comm.device:
-                comm.wait_stream(aux)
+        for aux in L.aux_streams_on(comm.device):
+            comm.wait_stream(aux)
         with torch.cuda.stream(comm):
             if self.exchange:
                 dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)

@@ -214,14 +214,21 @@ TIMER = None    # set to a KernelTimer() to record
 ERR_UNSUPPORTED = -3
 PACK_JOB_BYTES = 512
 SERIALIZE = os.environ.get("DVF_SERIALIZE", "0") == "1"   # True: no side streams (per-kernel timing passes, debugging)
-AUX_STREAMS = {}      # device -> auxiliary compute stream (dvf/steps.py runs the pose network on it)
+AUX_STREAMS = {}      # device (pose network, dvf/steps.py) or (device, name) -> auxiliary compute stream
 
 
-def aux_stream(device):
-    s = AUX_STREAMS.get(device)
+def aux_stream(device, name="pose"):
+    """Named auxiliary compute stream of a device: "pose" (the pose network runs beside the depth network, dvf/steps.py),
+    "heads" (the disparity heads run beside the next up-convolution, DispNetS.py)."""
+    key = device if name == "pose" else (device, name)
+    s = AUX_STREAMS.get(key)
     if s is None:
-        AUX_STREAMS[device] = s = torch.cuda.Stream(device=device)
+        AUX_STREAMS[key] = s = torch.cuda.Stream(device=device)
     return s
+
+
+def aux_streams_on(device):
+    return [s for k, s in AUX_STREAMS.items() if k == device or (isinstance(k, tuple) and k[0] == device)]
 
 
 def join_aux_streams():
@@ -229,9 +236,8 @@ def join_aux_streams():
     if not AUX_STREAMS:
         return
     cur = torch.cuda.current_stream()
-    for dev, s in AUX_STREAMS.items():
-        if dev == cur.device:
-            cur.wait_stream(s)
+    for s in aux_streams_on(cur.device):
+        cur.wait_stream(s)
 
 
 PACK_EPOCH = 0  # manual invalidation of every packed weight copy (FlatAdam bumps a per-parameter epoch instead: dvf/conv.py::_stamp)
