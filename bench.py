@@ -403,6 +403,10 @@ def main():
                                        "frac": a / PEAK_HBM_GBPS,
                                        "traffic": ((pmc_traffic("photo_fwd") or 0) + (pmc_traffic("photo_bwd") or 0) or None) if quoted else None,
                                        "algorithmic_bytes": p_by, "ms_per_step": p_ms,
+                                       "note": "algorithmic bytes assume every target pixel samples inside the source images; a "
+                                               "pixel projected out of view reads no source bytes, so on degenerate (random-"
+                                               "init) geometry the quotient overstates the traffic and can exceed the HBM peak "
+                                               "-- profiles/r02_photo_bench.txt has the kernels on KITTI-like geometry",
                                        "calls_per_step": ks.get("photo_fwd", {}).get("calls", 0) + ks.get("photo_bwd", {}).get("calls", 0)}
         result["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(ks.items())}
     if world > 1:
