@@ -1131,7 +1131,10 @@ int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qseg
     w.PCtot = o.PCtot; w.m_base = o.m_base; w.M = o.M; w.Cq = o.Cq;
     w.g_mstride = o.g_mstride; w.g_mbase = o.g_mbase; w.g_cbase = o.g_cbase; w.KK = o.KK; w.KH = o.KH; w.KW = o.KW;
     w.N = o.N; w.GH = o.GH; w.GW = o.GW; w.QH = o.QH; w.QW = o.QW; w.S = o.S; w.pad = o.pad;
-    const int MT = o.M > 32 ? 2 : 1, MB = 32 * MT, PF = (MB / 2) * WGP_PAIR;
+    // at most 16 gradient rows: 16x16x4 MFMA tiles (16 rows x 64*NTW columns per block) instead of half-empty 32-row tiles
+    static const bool no16 = dvf_tune("DVF_WG_TILE16") && atoi(dvf_tune("DVF_WG_TILE16")) == 0;      // tuning knob
+    const int TILE = (o.M <= 16 && !no16) ? 16 : 32;
+    const int MT = o.M > 32 ? 2 : 1, MB = TILE * MT, PF = (MB / 2) * WGP_PAIR;
     w.XA = (o.pad + 3) & ~3;
     w.RSq = roundup(w.XA + (WGP_BW - 1) * o.S + o.KW - o.pad, 4);
     w.PHq = (WGP_BH - 1) * o.S + o.KH;
@@ -1141,10 +1144,10 @@ int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qseg
     w.NPIq = cdiv(w.PHq * w.RSq, piece);
     if (w.NPIq > WGP_MAXQ) return DVF_ERR_UNSUPPORTED;
     w.PSq = w.NPIq * piece + 4;
-    // columns per block: 128 * NTW >= CK * T.  Cost ~ MFMA time = channel chunks x column tiles per chunk; balanced chunks.
+    // columns per block: 4 * NTW * TILE >= CK * T.  Cost ~ MFMA time = channel chunks x column tiles per chunk; balanced chunks.
     int best_cost = 1 << 30, NTW = 0, CK = 0;
-    for (int ntw = 2; ntw >= 1; --ntw) {
-        int ckmax = (128 * ntw) / T;
+    for (int ntw = (TILE == 16 ? 4 : 2); ntw >= 1; --ntw) {
+        int ckmax = (4 * ntw * TILE) / T;
         if (ckmax > o.Cq) ckmax = o.Cq;
         while (ckmax >= 1 && (size_t)2 * (PF + (size_t)(ckmax + 1) * w.PSq) * 4 > WGP_LDS_CAP) --ckmax;   // (+1: slot of ones)
         if (ckmax < 1) continue;
@@ -1167,13 +1170,13 @@ int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qseg
         return n;
     }();
     const int nblocks = w.W < ncu ? w.W : ncu;
-    w.bias_col = (dbias && CK * T < 128 * NTW) ? CK * T : -1;      // a spare column of the tile multiplies by ones
+    w.bias_col = (dbias && CK * T < 4 * NTW * TILE) ? CK * T : -1; // a spare column of the tile multiplies by ones
     w.dbias = w.bias_col >= 0 ? dbias : nullptr;
     w.QSLOTS = CK + (w.bias_col >= 0 ? 1 : 0);
     const size_t lds = (size_t)2 * (PF + (size_t)w.QSLOTS * w.PSq) * 4;
     if (const char *e = dvf_tune("DVF_WG_DBG")) w.dbg = atoi(e);
-    const int rc = dvf_wgrad_pipe_launch(w, MT, NTW, nblocks, lds, st);
-    if (rc == DVF_OK) dvf_plan_note(DVF_K_WGRAD_PIPE, MT, NTW, w.x4, CK, o.S, w.NPIq, nblocks, (int)lds, T, w.RSq, nseg);
+    const int rc = dvf_wgrad_pipe_launch(w, MT, NTW, nblocks, lds, st, TILE);
+    if (rc == DVF_OK) dvf_plan_note(DVF_K_WGRAD_PIPE, MT | (TILE << 8), NTW, w.x4, CK, o.S, w.NPIq, nblocks, (int)lds, T, w.RSq, nseg);
     if (rc == DVF_OK && bias_done) *bias_done = w.bias_col >= 0;
     return rc;
 }

@@ -16,7 +16,7 @@ struct WgpArgs {
     int64_t g_mstride;
     int g_mbase, g_cbase, KK, KH, KW;
     int N, GH, GW, QH, QW, S, pad;
-    int CK;              // Q channels per column chunk (CK * KK <= 128 * NTW columns)
+    int CK;              // Q channels per column chunk (CK * KK <= 4 * NTW * tile columns)
     int tilesX, tilesY, ntiles, mtiles, cchunks;
     int PHq, RSq, PSq, NPIq, XA;   // Q patch: rows, row stride, channel stride (floats), DMA pieces per channel, aligned left margin
     int x4;              // 1: 16-byte DMA lanes (GW % 4 == 0, QW % 4 == 0, 16-byte aligned bases), 0: 4-byte lanes
@@ -33,4 +33,5 @@ constexpr int WGP_MAXQ = 16;               // DMA pieces per Q patch channel
 constexpr size_t WGP_LDS_CAP = 160 * 1024;
 
 // (MT, NTW) in {1,2}^2; S in {1,2}.  Returns DVF_OK / DVF_ERR_*.
-int dvf_wgrad_pipe_launch(const WgpArgs &a, int MT, int NTW, int nblocks, size_t lds_bytes, hipStream_t st);
+// tile = 32: 32*MT rows x 128*NTW columns per block (NTW 1..2); tile = 16: 16 rows x 64*NTW columns (MT = 1, NTW 1..4)
+int dvf_wgrad_pipe_launch(const WgpArgs &a, int MT, int NTW, int nblocks, size_t lds_bytes, hipStream_t st, int tile = 32);

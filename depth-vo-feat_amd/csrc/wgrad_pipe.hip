@@ -29,11 +29,15 @@ using dvfp::tensor_rsrc;
 constexpr int WGP_THREADS = 512;           // 4 MFMA waves + 4 producers (one per SIMD)
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-template <int MT, int NTW, int S>
+// TILE = 32: v_mfma_f32_32x32x2_f32, 32*MT rows x 4*NTW*32 columns per block.  TILE = 16: v_mfma_f32_16x16x4_f32 (same
+// rate per SIMD, four pixels per instruction), 16*MT rows x 4*NTW*16 columns -- for layers whose gradient has at most 16 rows
+// (iconv1, the pose network's first convolution), where a 32-row tile is half padding.
+template <int MT, int NTW, int S, int TILE>
 __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a) {
-    constexpr int MB = 32 * MT, PF = (MB / 2) * WGP_PAIR;
+    constexpr int MB = TILE * MT, PF = (MB / 2) * WGP_PAIR;
+    constexpr int KQ = 64 / TILE;              // pixel groups of 4 per MFMA step: lane -> (tile row / column = lane % TILE, kq = lane / TILE)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, nl = lane & 31, kh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, nl = lane & (TILE - 1), kh = lane / TILE;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int stage_floats = PF + a.QSLOTS * a.PSq;
     const int nb = gridDim.x, b = blockIdx.x;
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
     int loff[NTW], cjv[NTW], tjv[NTW];
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
-        const int j = (wave * NTW + u) * 32 + nl;
+        const int j = (wave * NTW + u) * TILE + nl;
         const int cj = j / T, tj = j - cj * T, ta = tj / a.KW, tb = tj - ta * a.KW;
         const bool in_chunk = cj < a.CK;
         loff[u] = in_chunk ? cj * a.PSq + ta * a.RSq + tb + (a.XA - a.pad) : 0;
@@ -196,13 +200,15 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
             smem[stage_floats + PF + a.CK * a.PSq + e] = 1.f;
         }
     }
-    f32x16 acc[MT][NTW];
+    constexpr int NACC = TILE == 32 ? 16 : 4;  // accumulator registers of one MFMA tile
+    typedef float accv __attribute__((ext_vector_type(NACC)));
+    accv acc[MT][NTW];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int u = 0; u < NTW; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][u][r] = 0.f;
+            for (int r = 0; r < NACC; ++r) acc[m][u][r] = 0.f;
 
     auto consume = [&](int st) {
         const float *Pst = smem + st * stage_floats;
@@ -213,14 +219,16 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
         for (int u = 0; u < NTW; ++u) bp[u] = Qst + loff[u] + 4 * kh * S;
         f4 A[2][MT];
         float B[2][NTW][4];
-        // group `it` = 8 pixels: row y = it >> 2, columns 8*(it & 3) .. +7
+        // group `it` = 4*KQ pixels of a tile row (8 with the 32-wide tiles, 16 with the 16-wide ones): lane (., kq) holds
+        // pixels 4*kq .. 4*kq+3 of the group, MFMA step i multiplies component i of every kq
+        constexpr int GP = 4 * KQ, GPR = WGP_BW / GP;          // pixels per group, groups per tile row
         auto load = [&](auto bufc, int it) {
             constexpr int buf = decltype(bufc)::value;
-            const int y = it >> 2, tq = it & 3;
-            const float *ay = ap + y * 32 + 8 * tq;
+            const int y = it / GPR, tq = it - y * GPR;
+            const float *ay = ap + y * 32 + GP * tq;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) A[buf][m] = *reinterpret_cast<const f4 *>(ay + m * 16 * WGP_PAIR);
-            const int qo = (y * S) * a.RSq + 8 * tq * S;
+            for (int m = 0; m < MT; ++m) A[buf][m] = *reinterpret_cast<const f4 *>(ay + m * (TILE / 2) * WGP_PAIR);
+            const int qo = (y * S) * a.RSq + GP * tq * S;
 #pragma unroll
             for (int u = 0; u < NTW; ++u) {
                 const float *bg = bp[u] + qo;
@@ -235,12 +243,16 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int u = 0; u < NTW; ++u)
-                        acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[buf][m][i], B[buf][u][i], acc[m][u], 0, 0, 0);
+                    for (int u = 0; u < NTW; ++u) {
+                        if constexpr (TILE == 32)
+                            acc[m][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[buf][m][i], B[buf][u][i], acc[m][u], 0, 0, 0);
+                        else
+                            acc[m][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[buf][m][i], B[buf][u][i], acc[m][u], 0, 0, 0);
+                    }
         };
         using B0 = std::integral_constant<int, 0>;
         using B1 = std::integral_constant<int, 1>;
-        constexpr int NG = WGP_BH * WGP_BW / 8;
+        constexpr int NG = WGP_BH * WGP_BW / GP;
         load(B0{}, 0);
         for (int it = 0; it < NG; it += 2) {
             load(B1{}, it + 1);
@@ -255,6 +267,8 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
         const int m0 = mb * MB, c0 = cb * a.CK;
         const int nch = min(a.CK, a.Cq - c0);
         const bool full_m = m0 + MB <= a.M;                       // every row of the block exists: no per-element test
+        // accumulator register r of tile m is row  m*32 + (r & 3) + 8*(r >> 2) + 4*kh  (32x32)  /  m*16 + r + 4*kh  (16x16)
+        auto row_of = [](int m, int r) { return TILE == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) : m * 16 + r; };
 #pragma unroll
         for (int u = 0; u < NTW; ++u) {
             const bool colok = cjv[u] >= 0 && cjv[u] < nch && !DVF_DBG(a, 8);
@@ -264,8 +278,8 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = m * 32 + (r & 3) + 8 * (r >> 2);
+                    for (int r = 0; r < NACC; ++r) {
+                        const int ml = row_of(m, r);
                         if (full_m || m0 + 4 * kh + ml < a.M) atomicAdd(gl + (int64_t)ml * a.g_mstride, acc[m][u][r]);
                     }
             }
@@ -274,15 +288,15 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = m * 32 + (r & 3) + 8 * (r >> 2);
+                    for (int r = 0; r < NACC; ++r) {
+                        const int ml = row_of(m, r);
                         if (full_m || m0 + 4 * kh + ml < a.M) atomicAdd(bl + ml, acc[m][u][r]);
                     }
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][u][r] = 0.f;
+                for (int r = 0; r < NACC; ++r) acc[m][u][r] = 0.f;
         }
     };
     if (DVF_DBG(a, 64)) return;
@@ -298,33 +312,41 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
     }
 }
 
-template <int MT, int NTW, int S>
+template <int MT, int NTW, int S, int TILE>
 int launch_one(const WgpArgs &a, int nblocks, size_t lds, hipStream_t st) {
     static bool big_lds = false;
     if (lds > 64 * 1024 && !big_lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_pipe_kernel<MT, NTW, S>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_pipe_kernel<MT, NTW, S, TILE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)WGP_LDS_CAP) != hipSuccess)
             return DVF_ERR_LAUNCH;
         big_lds = true;
     }
-    wgrad_pipe_kernel<MT, NTW, S><<<nblocks, WGP_THREADS, lds, st>>>(a);
+    wgrad_pipe_kernel<MT, NTW, S, TILE><<<nblocks, WGP_THREADS, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? DVF_OK : DVF_ERR_LAUNCH;
 }
 
-template <int MT, int NTW>
+template <int MT, int NTW, int TILE>
 int launch_s(const WgpArgs &a, int nblocks, size_t lds, hipStream_t st) {
-    if (a.S == 1) return launch_one<MT, NTW, 1>(a, nblocks, lds, st);
-    if (a.S == 2) return launch_one<MT, NTW, 2>(a, nblocks, lds, st);
+    if (a.S == 1) return launch_one<MT, NTW, 1, TILE>(a, nblocks, lds, st);
+    if (a.S == 2) return launch_one<MT, NTW, 2, TILE>(a, nblocks, lds, st);
     return DVF_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
-int dvf_wgrad_pipe_launch(const WgpArgs &a, int MT, int NTW, int nblocks, size_t lds, hipStream_t st) {
+int dvf_wgrad_pipe_launch(const WgpArgs &a, int MT, int NTW, int nblocks, size_t lds, hipStream_t st, int tile) {
     if (nblocks < 1 || lds > WGP_LDS_CAP || a.NPIq > WGP_MAXQ) return DVF_ERR_UNSUPPORTED;
-    if (MT == 2 && NTW == 2) return launch_s<2, 2>(a, nblocks, lds, st);
-    if (MT == 2 && NTW == 1) return launch_s<2, 1>(a, nblocks, lds, st);
-    if (MT == 1 && NTW == 2) return launch_s<1, 2>(a, nblocks, lds, st);
-    if (MT == 1 && NTW == 1) return launch_s<1, 1>(a, nblocks, lds, st);
+    if (tile == 16) {                      // 16 rows x 64*NTW columns per block
+        if (MT != 1) return DVF_ERR_UNSUPPORTED;
+        if (NTW == 1) return launch_s<1, 1, 16>(a, nblocks, lds, st);
+        if (NTW == 2) return launch_s<1, 2, 16>(a, nblocks, lds, st);
+        if (NTW == 3) return launch_s<1, 3, 16>(a, nblocks, lds, st);
+        if (NTW == 4) return launch_s<1, 4, 16>(a, nblocks, lds, st);
+        return DVF_ERR_UNSUPPORTED;
+    }
+    if (MT == 2 && NTW == 2) return launch_s<2, 2, 32>(a, nblocks, lds, st);
+    if (MT == 2 && NTW == 1) return launch_s<2, 1, 32>(a, nblocks, lds, st);
+    if (MT == 1 && NTW == 2) return launch_s<1, 2, 32>(a, nblocks, lds, st);
+    if (MT == 1 && NTW == 1) return launch_s<1, 1, 32>(a, nblocks, lds, st);
     return DVF_ERR_UNSUPPORTED;
 }

@@ -47,6 +47,11 @@ CASES = [
     ("thin16_concat2_ragged", [16, 1], 16, 3, 1, 1, 0, False, 1, (2, 70, 75), None),
     ("thin16_concat3", [8, 13, 3], 16, 3, 1, 1, 0, False, 1, (1, 64, 66), None),
     ("thin16_single_noact", [16], 16, 3, 1, 1, 0, False, 0, (1, 65, 64), None),
+    # weight gradients with at most 16 rows: 16x16x4 MFMA tiles in wgrad_pipe (NTW 1..4, strides 1 / 2, both DMA widths)
+    ("wg16_c3x3", [5], 16, 3, 1, 1, 0, False, 1, (2, 24, 40), None),
+    ("wg16_c3x3_wide", [28], 12, 3, 1, 1, 0, False, 1, (1, 20, 37), None),
+    ("wg16_c7x7_s2", [6], 16, 7, 2, 3, 0, False, 1, (2, 32, 48), None),
+    ("wg16_c5x5_s2_odd", [9], 8, 5, 2, 2, 0, False, 0, (1, 23, 41), None),
     # thin stride-2 transposed convolutions (upconv1 / upconv2 of both networks): direct forward kernel
     ("dconvt3_16", [32], 16, 3, 2, 1, 1, True, 1, (2, 64, 66), None),
     ("dconvt3_16_crop", [64], 16, 3, 2, 1, 1, True, 1, (1, 64, 72), (127, 143)),
