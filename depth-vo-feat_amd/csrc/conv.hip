@@ -1131,10 +1131,6 @@ int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qseg
     w.PCtot = o.PCtot; w.m_base = o.m_base; w.M = o.M; w.Cq = o.Cq;
     w.g_mstride = o.g_mstride; w.g_mbase = o.g_mbase; w.g_cbase = o.g_cbase; w.KK = o.KK; w.KH = o.KH; w.KW = o.KW;
     w.N = o.N; w.GH = o.GH; w.GW = o.GW; w.QH = o.QH; w.QW = o.QW; w.S = o.S; w.pad = o.pad;
-    // at most 16 gradient rows: 16x16x4 MFMA tiles (16 rows x 64*NTW columns per block) instead of half-empty 32-row tiles
-    static const bool no16 = dvf_tune("DVF_WG_TILE16") && atoi(dvf_tune("DVF_WG_TILE16")) == 0;      // tuning knob
-    const int TILE = (o.M <= 16 && !no16) ? 16 : 32;
-    const int MT = o.M > 32 ? 2 : 1, MB = TILE * MT, PF = (MB / 2) * WGP_PAIR;
     w.XA = (o.pad + 3) & ~3;
     w.RSq = roundup(w.XA + (WGP_BW - 1) * o.S + o.KW - o.pad, 4);
     w.PHq = (WGP_BH - 1) * o.S + o.KH;
@@ -1144,16 +1140,31 @@ int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qseg
     w.NPIq = cdiv(w.PHq * w.RSq, piece);
     if (w.NPIq > WGP_MAXQ) return DVF_ERR_UNSUPPORTED;
     w.PSq = w.NPIq * piece + 4;
-    // columns per block: 4 * NTW * TILE >= CK * T.  Cost ~ MFMA time = channel chunks x column tiles per chunk; balanced chunks.
-    int best_cost = 1 << 30, NTW = 0, CK = 0;
-    for (int ntw = (TILE == 16 ? 4 : 2); ntw >= 1; --ntw) {
-        int ckmax = (4 * ntw * TILE) / T;
-        if (ckmax > o.Cq) ckmax = o.Cq;
-        while (ckmax >= 1 && (size_t)2 * (PF + (size_t)(ckmax + 1) * w.PSq) * 4 > WGP_LDS_CAP) --ckmax;   // (+1: slot of ones)
-        if (ckmax < 1) continue;
-        const int nch = cdiv(o.Cq, ckmax), cost = nch * ntw;
-        if (cost < best_cost) { best_cost = cost; NTW = ntw; CK = cdiv(o.Cq, nch); }
+    // Block shape: TILE*MT rows x 4*NTW*TILE columns, MFMA 32x32x2 (TILE 32) or 16x16x4 (TILE 16: same rate, a quarter of
+    // the tile).  Cost ~ matrix-pipe cycles of the layer = m-blocks x channel chunks x MT x NTW x (4 | 1); the 16-wide tiles
+    // only when they save >= 15 % (small row / column counts: a 32-wide tile would be mostly padding) -- per MFMA they read
+    // more LDS and re-stage more of P.  Channel chunks are balanced.
+    static const bool no16 = dvf_tune("DVF_WG_TILE16") && atoi(dvf_tune("DVF_WG_TILE16")) == 0;      // tuning knob
+    double best_cost = 1e30;
+    int TILE = 0, MT = 0, NTW = 0, CK = 0;
+    for (int tile = 32; tile >= 16; tile -= 16) {
+        if (tile == 16 && no16) break;
+        for (int mt = 2; mt >= 1; --mt) {
+            if (mt == 2 && o.M <= tile) continue;                 // (a second row tile would be empty)
+            const int pf = (tile * mt / 2) * WGP_PAIR;
+            for (int ntw = (tile == 16 ? 4 : 2); ntw >= 1; --ntw) {
+                int ckmax = (4 * ntw * tile) / T;
+                if (ckmax > o.Cq) ckmax = o.Cq;
+                while (ckmax >= 1 && (size_t)2 * (pf + (size_t)(ckmax + 1) * w.PSq) * 4 > WGP_LDS_CAP) --ckmax;   // (+1: slot of ones)
+                if (ckmax < 1) continue;
+                const int nch = cdiv(o.Cq, ckmax);
+                double cost = (double)cdiv(o.M, tile * mt) * nch * mt * ntw * (tile == 32 ? 4 : 1);
+                if (tile == 16) cost *= 1.15;
+                if (cost < best_cost) { best_cost = cost; TILE = tile; MT = mt; NTW = ntw; CK = cdiv(o.Cq, nch); }
+            }
+        }
     }
+    const int MB = TILE * MT, PF = (MB / 2) * WGP_PAIR;
     if (!NTW) return DVF_ERR_UNSUPPORTED;
     w.CK = CK;
     w.mtiles = cdiv(o.M, MB);

@@ -33,5 +33,5 @@ constexpr int WGP_MAXQ = 16;               // DMA pieces per Q patch channel
 constexpr size_t WGP_LDS_CAP = 160 * 1024;
 
 // (MT, NTW) in {1,2}^2; S in {1,2}.  Returns DVF_OK / DVF_ERR_*.
-// tile = 32: 32*MT rows x 128*NTW columns per block (NTW 1..2); tile = 16: 16 rows x 64*NTW columns (MT = 1, NTW 1..4)
+// tile = 32: 32*MT rows x 128*NTW columns per block (NTW 1..2); tile = 16: 16*MT rows x 64*NTW columns (NTW 1..4)
 int dvf_wgrad_pipe_launch(const WgpArgs &a, int MT, int NTW, int nblocks, size_t lds_bytes, hipStream_t st, int tile = 32);

@@ -336,12 +336,15 @@ int launch_s(const WgpArgs &a, int nblocks, size_t lds, hipStream_t st) {
 
 int dvf_wgrad_pipe_launch(const WgpArgs &a, int MT, int NTW, int nblocks, size_t lds, hipStream_t st, int tile) {
     if (nblocks < 1 || lds > WGP_LDS_CAP || a.NPIq > WGP_MAXQ) return DVF_ERR_UNSUPPORTED;
-    if (tile == 16) {                      // 16 rows x 64*NTW columns per block
-        if (MT != 1) return DVF_ERR_UNSUPPORTED;
-        if (NTW == 1) return launch_s<1, 1, 16>(a, nblocks, lds, st);
-        if (NTW == 2) return launch_s<1, 2, 16>(a, nblocks, lds, st);
-        if (NTW == 3) return launch_s<1, 3, 16>(a, nblocks, lds, st);
-        if (NTW == 4) return launch_s<1, 4, 16>(a, nblocks, lds, st);
+    if (tile == 16) {                      // 16*MT rows x 64*NTW columns per block
+        if (MT == 1 && NTW == 1) return launch_s<1, 1, 16>(a, nblocks, lds, st);
+        if (MT == 1 && NTW == 2) return launch_s<1, 2, 16>(a, nblocks, lds, st);
+        if (MT == 1 && NTW == 3) return launch_s<1, 3, 16>(a, nblocks, lds, st);
+        if (MT == 1 && NTW == 4) return launch_s<1, 4, 16>(a, nblocks, lds, st);
+        if (MT == 2 && NTW == 1) return launch_s<2, 1, 16>(a, nblocks, lds, st);
+        if (MT == 2 && NTW == 2) return launch_s<2, 2, 16>(a, nblocks, lds, st);
+        if (MT == 2 && NTW == 3) return launch_s<2, 3, 16>(a, nblocks, lds, st);
+        if (MT == 2 && NTW == 4) return launch_s<2, 4, 16>(a, nblocks, lds, st);
         return DVF_ERR_UNSUPPORTED;
     }
     if (MT == 2 && NTW == 2) return launch_s<2, 2, 32>(a, nblocks, lds, st);
