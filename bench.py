@@ -45,9 +45,16 @@ CONFIGS = {
 }
 
 
+REAL_STDOUT = sys.stdout
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) ourselves.  This parent
     has made no GPU call; it relays rank 0's JSON line and exits with the worst return code."""
+    import torch
+    have = torch.cuda.device_count()        # (does not initialise the GPU in this parent)
+    if have < n:
+        sys.exit(f"bench.py: --gpus {n} but this host exposes {have} GPU(s)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -59,8 +66,8 @@ def spawn_ranks(n):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
+    REAL_STDOUT.write(out.decode())
+    REAL_STDOUT.flush()
     sys.exit(max(abs(rc) for rc in rcs))
 
 
@@ -214,6 +221,13 @@ def cpu_baseline():
 
 
 def main():
+    # stdout carries exactly ONE JSON line (the driver's contract).  The GPU boxes export NCCL_DEBUG=VERSION, which makes RCCL
+    # printf its version banner to stdout at the first collective (NCCL_DEBUG_FILE does not move it): file descriptor 1 is
+    # pointed at stderr for the whole run and the JSON line goes to a saved copy of the real stdout.
+    global REAL_STDOUT
+    sys.stdout.flush()
+    REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -253,6 +267,8 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} or without a launcher")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants GPU {local_rank}, this host exposes {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or args.force_ddp:
@@ -417,8 +433,8 @@ def main():
         log("cpu baseline")
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(result))
-        sys.stdout.flush()
+        print(json.dumps(result), file=REAL_STDOUT)
+        REAL_STDOUT.flush()
     if world > 1 or args.force_ddp:
         dist.barrier()
         dist.destroy_process_group()
