@@ -388,9 +388,12 @@ def main():
         # every rank runs the extra eager steps (they contain the gradient all-reduce); rank 0 records
         if rank == 0:
             ks = measure_kernels(step)
-        else:
+        else:                               # the same two serialised steps (same schedule, same collective order) on every rank
+            from dvf import lib as _Lr
+            _Lr.SERIALIZE = True
             step()
             step()
+            _Lr.SERIALIZE = False
     if rank == 0 and ks is not None:
         g_ms = ks.get("conv_fwd", {}).get("ms", 0) + ks.get("conv_dgrad", {}).get("ms", 0)
         g_fl = ks.get("conv_fwd", {}).get("flops", 0) + ks.get("conv_dgrad", {}).get("flops", 0)

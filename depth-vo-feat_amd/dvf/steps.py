@@ -20,21 +20,20 @@ def _side_by_side(aux_fn, main_fn):
     CUs, so the two fill each other's gaps; autograd runs each backward on its forward stream, so the backward passes
     overlap too.  FlatAdam.step() joins the auxiliary stream (dvf/lib.py AUX_STREAMS).  DVF_POSE_STREAM=0 disables."""
     if L.SERIALIZE or os.environ.get("DVF_POSE_STREAM", "1") == "0":
-        return aux_fn(), main_fn()
+        # same HOST order as below (depth network first): the order in which gradient buckets become ready -- and with it
+        # the order of the all-reduce calls -- must not depend on this switch (bench.py times rank 0 serialised while the
+        # other ranks run the overlapped schedule: mismatched collective orders would hang RCCL)
+        m_out = main_fn()
+        return aux_fn(), m_out
     cur = torch.cuda.current_stream()
     aux = L.aux_stream(cur.device)
     aux.wait_stream(cur)
     # Host order: the depth network first, the pose network LAST.  Autograd runs ready nodes latest-created first, so the
     # pose network's whole backward pass is enqueued (on its own stream) before the depth network's and overlaps it from
     # the start; the other order leaves it -- and its weight gradients, Adam and repack -- as a serial tail of the step.
-    if os.environ.get("DVF_POSE_FIRST", "0") == "1":      # (the round-1 order, for A/B runs)
-        with torch.cuda.stream(aux):
-            a_out = aux_fn()
-        m_out = main_fn()
-    else:
-        m_out = main_fn()
-        with torch.cuda.stream(aux):
-            a_out = aux_fn()
+    m_out = main_fn()
+    with torch.cuda.stream(aux):
+        a_out = aux_fn()
     cur.wait_stream(aux)
 
     def _mark(t):
