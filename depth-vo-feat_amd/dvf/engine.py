@@ -86,6 +86,7 @@ class FlatAdam:
         self._reset_pending()
         self.side = torch.cuda.Stream(device=dev) if (wgrad_stream and dev.type == "cuda") else None
         self._sides = {}         # compute stream -> its weight-gradient stream (the main stream's is self.side)
+        self._fork_cache = {}    # raw stream handle -> [stream object, side stream, event ring, next slot]
         self._side_dirty = False
         self._keep = []          # tensors read by side-stream kernels, kept alive until the join
 
@@ -95,11 +96,20 @@ class FlatAdam:
         (or None: run on the current stream).  ``tensors`` are kept alive until ``join_wgrad``."""
         if self.side is None or L.SERIALIZE:
             return None
-        cur = torch.cuda.current_stream()
-        side = self._sides.get(cur.cuda_stream)
-        if side is None:         # one per compute stream: a sub-network on the auxiliary stream gets its own
-            side = self._sides[cur.cuda_stream] = self.side if not self._sides else torch.cuda.Stream(device=cur.device)
-        ev = torch.cuda.Event()
+        # (host cost matters: this runs once per convolution of the backward pass.  The raw stream handle keys a cache of
+        # (stream object, side stream, ring of reusable events): a wait captures the event's state when it is enqueued, so
+        # re-recording a ring slot later does not disturb an earlier wait.)
+        raw = L.stream().value
+        ent = self._fork_cache.get(raw)
+        if ent is None:
+            cur = torch.cuda.current_stream()
+            side = self._sides.get(cur.cuda_stream)
+            if side is None:     # one per compute stream: a sub-network on the auxiliary stream gets its own
+                side = self._sides[cur.cuda_stream] = self.side if not self._sides else torch.cuda.Stream(device=cur.device)
+            ent = self._fork_cache[raw] = [cur, side, [torch.cuda.Event() for _ in range(32)], 0]
+        cur, side, ring, i = ent
+        ent[3] = (i + 1) & 31
+        ev = ring[i]
         ev.record(cur)
         side.wait_event(ev)
         self._keep.extend(t for t in tensors if t is not None)
