@@ -1385,7 +1385,9 @@ int dvf_act_bwd2(const float *dy, const float *y, float *dpre, float *dbias, int
     int chunks = (HW + 8191) / 8192;
     const int64_t planes = (int64_t)N * C;
     while (chunks > 1 && planes * chunks > 16384) chunks >>= 1;
-    while (planes * chunks < 1024 && HW / (chunks * 2) >= 1024) chunks *= 2;    // small layers: still fill the GPU
+    // small layers: still fill the GPU -- but every block ends in ONE float atomic on dbias[c], and atomics on one address
+    // serialise (~40 ns each: 1024 blocks of a 1-channel head cost 41 us for a 10 MB pass): at most ~128 blocks per channel
+    while (planes * chunks < 1024 && HW / (chunks * 2) >= 1024 && (!dbias || (int64_t)N * chunks * 2 <= 128)) chunks *= 2;
     if (vec) act_bwd_kernel<true><<<(unsigned)(planes * chunks), 256, 0, st>>>(dy, y, dpre, dbias, C, HW, act, alpha, beta, chunks);
     else act_bwd_kernel<false><<<(unsigned)(planes * chunks), 256, 0, st>>>(dy, y, dpre, dbias, C, HW, act, alpha, beta, chunks);
     DVF_LAUNCH_CHECK();
