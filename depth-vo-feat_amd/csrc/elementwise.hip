@@ -37,8 +37,17 @@ __global__ void resize_bilinear_fwd_kernel(const float *in, float *out, int H, i
 // Gather-form backward for the x2 case: input pixel (y, x) collects from output rows 2y-1 .. 2y+2.
 __global__ void upsample2x_bwd_kernel(const float *gout, float *gin, int H, int W, int OH, int OW, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % W), y = (int)((i / W) % H);
-        const int64_t plane = i / ((int64_t)W * H);
+        int x, y;
+        int64_t plane;
+        if (total < ((int64_t)1 << 31)) {      // 32-bit index arithmetic (three 64-bit divisions per element were most of the kernel)
+            const unsigned i32 = (unsigned)i, row = i32 / (unsigned)W;
+            x = (int)(i32 - row * (unsigned)W);
+            plane = row / (unsigned)H;
+            y = (int)(row - (unsigned)plane * (unsigned)H);
+        } else {
+            x = (int)(i % W); y = (int)((i / W) % H);
+            plane = i / ((int64_t)W * H);
+        }
         const float *g = gout + plane * OH * OW;
         float wy[4], wx[4];
 #pragma unroll
