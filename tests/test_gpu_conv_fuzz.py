@@ -1,4 +1,4 @@
-"""Randomised envelope test of the weight-gradient path (wgrad_pipe.hip + its fallbacks): 48 seeded geometries -- kernel
+"""Randomised envelope tests of the convolution paths (weight gradients: wgrad_pipe.hip + its fallbacks; forward and (masked) dgrad): 48 seeded geometries -- kernel
 sizes 1..7, strides 1/2, Conv2d and ConvTranspose2d, 1..3 input segments, odd sizes down to 2x3 pixels, channel counts on
 both sides of the 16 / 32 / 64-row tile boundaries, with and without the fused bias column -- against torch CPU.
 Bound: 1e-4 relative (max-abs error / max-abs reference), fp32."""
