@@ -1516,8 +1516,7 @@ static int dgrad_all(const dvf_conv_desc *d, const float *dpre, const float *pac
     if (dvf_head_applicable(d, nseg)) {
         if (!din_segs[0]) return DVF_OK;
         if (!w) return DVF_ERR_INVALID_ARG;
-        const int rc = dvf_head_dgrad(d, dpre, w, din_segs[0], st);
-        return rc ? rc : postpass(0);
+        return dvf_head_dgrad(d, dpre, w, din_segs[0], st, mask_segs ? mask_segs[0] : nullptr);     // (mask applied in the kernel)
     }
     PipeOp op;
     int off = 0;

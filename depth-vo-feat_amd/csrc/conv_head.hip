@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const 
 // din[n][c][y][x] = sum_mo sum_taps w[mo][c][ta][tb] * dpre[n][mo][y-ta+1][x-tb+1]
 template <int MO>
 __global__ __launch_bounds__(256) void head_dgrad_kernel(const float *__restrict__ dpre, const float *__restrict__ w,
-                                                         float *__restrict__ din, int C, int H, int W, int tilesX) {
+                                                         float *__restrict__ din, int C, int H, int W, int tilesX,
+                                                         const float *__restrict__ mask) {
     __shared__ float tile[MO * HP_H * HP_W];
     const int n = blockIdx.y, tY = blockIdx.x / tilesX, tX = blockIdx.x - tY * tilesX;
     const int y0 = tY * HT_H, x0 = tX * HT_W;
@@ -173,7 +174,9 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float *__restrict
             for (int b = 0; b < 3; ++b) g[m][a * 3 + b] = tile[m * (HP_H * HP_W) + (ly + 2 - a) * HP_W + (lx + 2 - b)];
     const int y = y0 + ly, x = x0 + lx;
     if (y >= H || x >= W) return;
-    float *dst = din + (int64_t)n * C * plane + (int64_t)y * W + x;
+    const int64_t base = (int64_t)n * C * plane + (int64_t)y * W + x;
+    float *dst = din + base;
+    const float *mk = mask ? mask + base : nullptr;     // ReLU backward of the layer that produced the input: its output is the mask
     for (int c = 0; c < C; ++c) {
         float s = 0.f;
 #pragma unroll
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float *__restrict
 #pragma unroll
             for (int k = 0; k < 9; ++k) s = fmaf(wm[k], g[m][k], s);
         }
+        if (mk) s = mk[c * plane] > 0.f ? s : 0.f;
         dst[c * plane] = s;
     }
 }
@@ -432,10 +436,10 @@ int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w
     return DVF_OK;
 }
 
-int dvf_head_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, hipStream_t st) {
+int dvf_head_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, hipStream_t st, const float *mask) {
     const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, HT_H);
     const dim3 grid(tilesX * tilesY, d->N);
-    HEAD_DISPATCH(d->C_out, (head_dgrad_kernel<MO><<<grid, 256, 0, st>>>(dpre, w, din, d->C_in, d->H_in, d->W_in, tilesX)));
+    HEAD_DISPATCH(d->C_out, (head_dgrad_kernel<MO><<<grid, 256, 0, st>>>(dpre, w, din, d->C_in, d->H_in, d->W_in, tilesX, mask)));
     DVF_LAUNCH_CHECK();
     dvf_plan_note(DVF_K_HEAD_DGRAD, d->C_out);
     return DVF_OK;
