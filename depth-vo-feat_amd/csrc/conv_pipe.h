@@ -289,23 +289,28 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
         avec af[2][MT];                                    // A fragments: ping-pong by tap (one tap ahead)
         float bf[2][TBU][NT][VW];                          // B fragments: ping-pong by unit (one unit ahead)
         int lta = 0, lcpg = 0, lk = 0;                     // load iterator (scalar): next unit to fetch
-        auto load_b = [&](auto bufc) {
-            constexpr int buf = decltype(bufc)::value;
+        // B rows of the next unit for channel pair j (all tiles): TBU consecutive floats of one patch row each
+        auto load_bj = [&](auto bufc, auto jc) {
+            constexpr int buf = decltype(bufc)::value, j = decltype(jc)::value;
             const float *prow0 = patch + (lta * RS + lcpg * (2 * VW) * PSR);
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
+            for (int i = 0; i < NT; ++i) {
+                const float *prow = prow0 + bj[i][j];
+                if constexpr (IS == 1) {
 #pragma unroll
-                for (int j = 0; j < VW; ++j) {
-                    const float *prow = prow0 + bj[i][j];
-                    if constexpr (IS == 1) {
+                    for (int u = 0; u < TBU; ++u) bf[buf][u][i][j] = prow[u];
+                } else {
+                    const float *prow2 = prow + PWH;       // odd columns of the de-interleaved row
 #pragma unroll
-                        for (int u = 0; u < TBU; ++u) bf[buf][u][i][j] = prow[u];
-                    } else {
-                        const float *prow2 = prow + PWH;   // odd columns of the de-interleaved row
-#pragma unroll
-                        for (int u = 0; u < TBU; ++u) bf[buf][u][i][j] = (u & 1) ? prow2[u >> 1] : prow[u >> 1];
-                    }
+                    for (int u = 0; u < TBU; ++u) bf[buf][u][i][j] = (u & 1) ? prow2[u >> 1] : prow[u >> 1];
                 }
+            }
+        };
+        auto load_b = [&](auto bufc) {
+            load_bj(bufc, std::integral_constant<int, 0>{});
+            if constexpr (VW > 1) load_bj(bufc, std::integral_constant<int, 1>{});
+            if constexpr (VW > 2) load_bj(bufc, std::integral_constant<int, 2>{});
+            if constexpr (VW > 3) load_bj(bufc, std::integral_constant<int, 3>{});
         };
         // A fragments of tap u of unit `unit` (scalar) into ping-pong buffer tp
         auto load_a = [&](auto tpc, int unit, auto uc) {
@@ -320,33 +325,50 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
             lcpg = wrap ? 0 : lcpg + 1;
             lta += wrap ? 1 : 0;
         };
-        auto mma_tap = [&](auto bufc, auto tpc, auto uc) {
-            constexpr int buf = decltype(bufc)::value, tp = decltype(tpc)::value, u = decltype(uc)::value;
+        // the MT*NT MFMAs of channel pair j of tap u
+        auto mma_j = [&](auto bufc, auto tpc, auto uc, auto jc) {
+            constexpr int buf = decltype(bufc)::value, tp = decltype(tpc)::value, u = decltype(uc)::value, j = decltype(jc)::value;
 #pragma unroll
-            for (int j = 0; j < VW; ++j)
+            for (int m = 0; m < MT; ++m) {
+                float av;
+                if constexpr (VW == 1) av = af[tp][m]; else av = af[tp][m][j];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    float av;
-                    if constexpr (VW == 1) av = af[tp][m]; else av = af[tp][m][j];
-#pragma unroll
-                    for (int i = 0; i < NT; ++i)
-                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[buf][u][i][j], acc[m][i], 0, 0, 0);
-                }
+                for (int i = 0; i < NT; ++i)
+                    acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[buf][u][i][j], acc[m][i], 0, 0, 0);
+            }
         };
         using B0 = std::integral_constant<int, 0>;
         using B1 = std::integral_constant<int, 1>;
-        // tap by tap: this unit's MFMAs of tap u, then the loads behind them: the A fragments of the NEXT tap (this unit's
-        // tap u+1, or the next unit's tap 0) and, behind tap 0, all B rows of the next unit.  lk = index of the next unit.
-        // Keeping A only one tap ahead (not a whole unit) saves 32-48 VGPRs: 135 instead of 183 for the 3x3 / 8-channel
-        // variant, i.e. three waves per SIMD = two blocks per CU.  The scheduling barriers keep hipcc from sinking the
-        // loads next to their uses.
+        // Tap by tap: behind the first MFMA group (channel pair 0) of tap u go the A fragments of the NEXT tap (this unit's
+        // tap u+1, or the next unit's tap 0) and, in tap 0, the B rows of the next unit follow pair by pair behind the
+        // groups.  lk = index of the next unit.  Keeping A only one tap ahead (not a whole unit) saves 32-48 VGPRs.  The
+        // scheduling barriers pin this order: hipcc otherwise sinks the reads next to their uses.  Measured in isolation
+        // (tools/micro/pipe_loop.hip, profiles/r03_pipe_loop.txt): this loop runs at 66.5 cycles per MFMA (64 = the pipe's
+        // rate) with the reads here OR behind the last group (round 2's order) -- the loop was never the limiter.
         auto step = [&](auto bufc, auto nbufc, auto pbc, auto uc) {
             constexpr int u = decltype(uc)::value, tp = (decltype(pbc)::value + u) & 1;
-            mma_tap(bufc, std::integral_constant<int, tp>{}, uc);
-            if constexpr (u == 0) load_b(nbufc);
+            using TP = std::integral_constant<int, tp>;
+            mma_j(bufc, TP{}, uc, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (u + 1 < TBU) load_a(std::integral_constant<int, tp ^ 1>{}, lk - 1, std::integral_constant<int, u + 1>{});
             else load_a(std::integral_constant<int, tp ^ 1>{}, lk, std::integral_constant<int, 0>{});
+            if constexpr (u == 0) load_bj(nbufc, std::integral_constant<int, 0>{});
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (VW > 1) {
+                mma_j(bufc, TP{}, uc, std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (u == 0) { load_bj(nbufc, std::integral_constant<int, 1>{}); __builtin_amdgcn_sched_barrier(0); }
+            }
+            if constexpr (VW > 2) {
+                mma_j(bufc, TP{}, uc, std::integral_constant<int, 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (u == 0) { load_bj(nbufc, std::integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0); }
+            }
+            if constexpr (VW > 3) {
+                mma_j(bufc, TP{}, uc, std::integral_constant<int, 3>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (u == 0) { load_bj(nbufc, std::integral_constant<int, 3>{}); __builtin_amdgcn_sched_barrier(0); }
+            }
         };
         auto unit = [&](auto bufc, auto nbufc, auto pbc) {
             step(bufc, nbufc, pbc, std::integral_constant<int, 0>{});
