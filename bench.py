@@ -48,26 +48,60 @@ CONFIGS = {
 REAL_STDOUT = sys.stdout
 
 
+def count_gpus_sysfs():
+    """GPUs of this host counted WITHOUT touching the HIP/HSA runtime: KFD topology nodes with SIMDs (CPU nodes have
+    simd_count 0).  Returns None when the topology is not readable (then the rank processes find out for themselves)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                for line in f:
+                    k, _, v = line.partition(" ")
+                    if k == "simd_count" and int(v) > 0:
+                        n += 1
+        return n
+    except OSError:
+        return None
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) ourselves.  This parent
-    has made no GPU call; it relays rank 0's JSON line and exits with the worst return code."""
-    import torch
-    have = torch.cuda.device_count()        # (does not initialise the GPU in this parent)
-    if have < n:
+    makes NO GPU-runtime call -- not even a device count through torch, which loads HIP/HSA: on this pool a process that
+    has initialised the GPU must not exec another program, and the ranks are fork+exec'd from here.  It polls all ranks:
+    the first one to fail takes the others down (a crashed rank would otherwise leave its peers in the rendezvous or in a
+    collective until their timeout); it relays rank 0's JSON line and exits with the worst return code."""
+    import time
+    have = count_gpus_sysfs()
+    if have is not None and have < n:
         sys.exit(f"bench.py: --gpus {n} but this host exposes {have} GPU(s)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    REAL_STDOUT.write(out.decode())
+    out_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dvf_bench_rank0_{os.getpid()}.json")
+    with open(out_path, "wb") as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rcs = [None] * n
+    failed = False
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+                if rcs[i] not in (None, 0) and not failed:
+                    failed = True
+                    for q in procs:                     # exactly the processes started above
+                        if q.poll() is None:
+                            q.terminate()
+        time.sleep(0.05)
+    with open(out_path, "rb") as f:
+        REAL_STDOUT.write(f.read().decode())
     REAL_STDOUT.flush()
+    os.unlink(out_path)
     sys.exit(max(abs(rc) for rc in rcs))
 
 

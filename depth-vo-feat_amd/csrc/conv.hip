@@ -1634,4 +1634,16 @@ int dvf_conv2d_pack_batch(const void *jobs_dev, const int *block_prefix_dev, con
     return DVF_OK;
 }
 
+#ifdef DVF_TUNING
+// (tuning build only, not part of include/dvf_hip.h) the cycle account of the last pipelined launch made with DVF_STAMPS
+// set: 8 x u64 per block (conv_pipe.h), copied to the host after a device synchronisation.  Returns the block count.
+int dvf_tuning_read_stamps(unsigned long long *out, int max_blocks) {
+    if (!out || !g_stamp_buf) return 0;
+    const int nb = g_stamp_blocks < max_blocks ? g_stamp_blocks : max_blocks;
+    if (hipDeviceSynchronize() != hipSuccess) return DVF_ERR_LAUNCH;
+    if (hipMemcpy(out, g_stamp_buf, (size_t)nb * 64, hipMemcpyDeviceToHost) != hipSuccess) return DVF_ERR_LAUNCH;
+    return nb;
+}
+#endif
+
 }  // extern "C"

@@ -21,6 +21,17 @@
 
 namespace dvfp {
 
+// In-kernel cycle stamps (tuning build only; the product kernel contains none): s_memtime + its own lgkmcnt(0).
+#ifdef DVF_TUNING
+#define DVF_STAMP(a, var) do { if ((a).stamps) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); } while (0)
+#define DVF_STAMP_RT(a, var) do { if ((a).stamps) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); } while (0)
+#define DVF_STAMPS_ON 1
+#else
+#define DVF_STAMP(a, var) do { } while (0)
+#define DVF_STAMP_RT(a, var) do { } while (0)
+#define DVF_STAMPS_ON 0
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
@@ -62,8 +73,10 @@ struct PipeArgs {
     int KS, NCH, out_mode, NG;            // out_mode 0: bias+act store, 1: atomicAdd, 2: plain partial store at ks*ws_slice
     int64_t ws_slice;
     int lsw, lsh, TGX, TGY, BW, BH, BN, tilesX, tilesY;
+    int x4;                               // patch DMA in 16-byte lanes (see pipe_geo)
     int SLmax, PSRmax, NST;               // LDS carve per stage (NST = 2 or 3 stages): SLmax weight floats | CK * PSRmax patch floats
     int dbg;                              // ablation switches (tools/conv_bench.py): 1 no patch loads, 2 no weight loads, 4 no MFMA
+    unsigned long long *stamps;           // -DDVF_TUNING builds: per-block cycle account (8 x u64 per block), or NULL
     // dgrad of a segment produced by a ReLU layer (out_mode 0): out = (mask > 0) ? v : 0 and dbias[channel] += sum(out) --
     // the activation backward pass and the bias gradient of the PRODUCING layer, done where its gradient is born
     const float *mask;                    // same shape as out (the producing layer's output), or NULL
@@ -80,12 +93,34 @@ __host__ __device__ inline int pipe_row_stride(int RSu, int SW, int SH, int IS) 
     return (padded * 8 <= RSu * 9) ? padded : RSu;
 }
 
-struct PipeGeo { int PH, PW, PWH, RS, PSR, NPI; };
-__host__ __device__ inline PipeGeo pipe_geo(int BH, int BW, int BN, int IS, int TA, int TB, int SW, int SH) {
+struct PipeGeo { int PH, PW, PWH, RS, PSR, NPI, XA; };
+// x4 = 0: 4-byte DMA lanes, pieces of 64 floats, stride-2 rows de-interleaved (even columns | odd columns).
+// x4 = 1: 16-byte DMA lanes, pieces of 256 floats.  A patch row starts at the 16-byte-aligned image column at or left of
+//         the first one the tile needs (XA = 0..3 floats of left margin) and is a multiple of 4 floats long, so a lane's four
+//         floats never straddle a row or the image border (IW % 4 == 0, (BW * IS) % 4 == 0: the planner checks).  Rows are
+//         kept in image order also for stride 2: the B fragments are then read with a lane stride of two floats (a 2-way
+//         bank conflict on ds_read_b32, which the LDS has room for) instead of being de-interleaved by 4-byte lanes.
+__host__ __device__ inline PipeGeo pipe_geo(int BH, int BW, int BN, int IS, int TA, int TB, int SW, int SH, int x4 = 0, int bx = 0) {
     PipeGeo g;
     g.PH = (BH - 1) * IS + TA;
     g.PW = (BW - 1) * IS + TB;
     g.PWH = (g.PW + 1) >> 1;
+    g.XA = 0;
+    if (x4) {
+        g.XA = ((bx % 4) + 4) % 4;
+        int rs = (g.XA + g.PW + 3) & ~3;
+        // rows of the SW x SH sub-tile are IS*RS floats apart: IS*RS == IS*SW (mod 32) spreads them over the banks;
+        // only when that costs at most 1/8 more LDS (RS stays a multiple of 4)
+        if (SH > 1 && SW < 32 && (SW & 3) == 0) {
+            int padded = rs;
+            while (((padded * IS) & 31) != ((SW * IS) & 31) && padded < rs + 32) padded += 4;
+            if (((padded * IS) & 31) == ((SW * IS) & 31) && padded * 8 <= rs * 9) rs = padded;
+        }
+        g.RS = rs;
+        g.PSR = (BN * g.PH * g.RS + 255) & ~255;
+        g.NPI = g.PSR >> 8;
+        return g;
+    }
     g.RS = pipe_row_stride(IS == 2 ? 2 * g.PWH : g.PW, SW, SH, IS);
     g.PSR = (BN * g.PH * g.RS + 63) & ~63;
     g.NPI = g.PSR >> 6;
@@ -125,32 +160,78 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
     if (oy0 >= c.OHc || ox0 >= c.OWc) return;              // tile outside this (smaller) class: whole block exits
     const int mb = blockIdx.y;
     const int SW = 1 << a.lsw, SH = 1 << a.lsh;
-    const PipeGeo geo = pipe_geo(a.BH, a.BW, a.BN, a.IS, c.TA, TBU, SW, SH);   // TBU >= TB columns staged
+    const PipeGeo geo = pipe_geo(a.BH, a.BW, a.BN, a.IS, c.TA, TBU, SW, SH, a.x4, c.bx);   // TBU >= TB columns staged
     const int RS = geo.RS, PSR = geo.PSR, PWH = geo.PWH;
     const int g_begin = (int)(((int64_t)a.NCH * ks) / a.KS), g_end = (int)(((int64_t)a.NCH * (ks + 1)) / a.KS);
+    // cycle account of this block (tuning build): [0] prologue [1] chunk loop [2] of it: MFMA wave 0 at the chunk barriers
+    // [3] epilogue [4] 100 MHz ticks entry -> end  [5] producer 0: waiting for its DMA (vmcnt)  [6] at the barriers  [7] issuing
+    unsigned long long t_entry = 0, r_entry = 0;
+    const int lin_block = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    DVF_STAMP(a, t_entry);
+    DVF_STAMP_RT(a, r_entry);
 
     if (wave >= 4) {
         // ================================================================== producer waves: all LDS-DMA loads
-        // Issuing an LDS-DMA instruction stalls the SIMD's issue port for ~60 cycles, which the MFMA wave sharing that
-        // SIMD loses (measured: full kernel = MFMA-only time + 25-30 % with two producers on SIMDs 0 and 1, while the
-        // block advances at the pace of its slowest MFMA wave).  Blocks that own a whole CU anyway are launched with FOUR
-        // producers, one per SIMD: producers 2*par and 2*par+1 share the chunks of parity `par`, half the pieces each.
-        const int nprod = (int)(blockDim.x >> 6) - 4, pidx = wave - 4;
-        const int par = nprod == 2 ? pidx : (pidx >> 1);   // this producer owns chunks x with x % 2 == par ...
-        const int half = nprod == 2 ? 0 : (pidx & 1), nhalf = nprod == 2 ? 1 : 2;     // ... and this share of their pieces
-        const int NWP = c.SL >> 8;                         // 1 KiB weight pieces per chunk
-        const int iy0 = oy0 * a.IS + c.by, ix0 = ox0 * a.IS + c.bx;
-        unsigned pvoff[PIPE_MAXNPI];                       // per-lane source offset of every patch piece
-        int pbn[PIPE_MAXNPI];
+        // Issuing an LDS-DMA instruction stalls the SIMD's issue port for ~40 cycles, which the MFMA wave sharing that
+        // SIMD loses.  Blocks that own a whole CU anyway are launched with FOUR producers, one per SIMD: producers 2*par
+        // and 2*par+1 share the chunks of parity `par`, half the pieces each.
+        //
+        // Round 3: the in-kernel cycle account (tools/r3/stamps.py, profiles/r03_pipe_stamps.txt) showed the MFMA waves
+        // waiting at the chunk barriers for 20-60 % of the loop -- not for memory (the producers' vmcnt waits were < 1 us
+        // per launch) but for the producers' own INSTRUCTION STREAM: per chunk hipcc had hoisted 32 v_mad_u64 + 32
+        // v_cndmask + 30 v_readlane (the per-piece "image index x image stride" of the BN > 1 form, with its 64 lane-mask
+        // SGPRs spilled) in front of a compare-and-branch chain per piece -- 0.4-0.65 us per CHANNEL whatever the lane
+        // width, against 40 cycles per DMA instruction in isolation (tools/micro/dma_rate.hip).  Now every per-lane
+        // quantity is formed when the producer ENTERS A SEGMENT of the (virtual) input concatenation, the piece loops have
+        // compile-time trip counts, channel tails are zero-filled through a descriptor with no records (same
+        // instructions, no per-lane select), and a chunk costs: 1 scalar add + 1 DMA per piece.
+        // Everything the issue loops touch is wave-uniform; hipcc does not always see that (the class record is read
+        // with a run-time index), and ONE value it takes for divergent turns the DMA loops into waterfall loops with
+        // their addresses in VGPRs (3x slower kernels).  readfirstlane pins the scalars.
+        auto U = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+        const int nprod = U((int)(blockDim.x >> 6) - 4), pidx = wave - 4;
+        const int par = U(nprod == 2 ? pidx : (pidx >> 1));   // this producer owns chunks x with x % 2 == par ...
+        const int half = U(nprod == 2 ? 0 : (pidx & 1)), nhalf = U(nprod == 2 ? 1 : 2);     // ... and this share of their pieces
+        const int NWP = U(c.SL >> 8);                      // 1 KiB weight pieces per chunk
+        const int iy0 = U(oy0 * a.IS + c.by), ix0 = U(ox0 * a.IS + c.bx);
+        const int sfl = U(stage_floats), PSRu = U(PSR), NPIu = U(geo.NPI), SLu = U(c.SL), SLmaxu = U(a.SLmax);
+        const unsigned wbase = (unsigned)U((int)(c.wp_off + (unsigned)(mb * a.NCH) * (unsigned)c.SL));
+        const __amdgpu_buffer_rsrc_t rs_w = tensor_rsrc(a.wp);
+        auto issue_w = [&](int g, int st) __attribute__((always_inline)) {
+            if (DVF_DBG(a, 2)) return;
+            float *wl = smem + st * sfl;
+            unsigned so = ((wbase + (unsigned)g * (unsigned)SLu) << 2) + ((unsigned)half << 10);
+            float *dst = wl + (half << 8);
+            for (int p = half; p < NWP; p += nhalf) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)dst, 16, (unsigned)lane << 4, so, 0, 0);
+                so += (unsigned)nhalf << 10;
+                dst += nhalf << 8;
+            }
+        };
+        // Chunk x (counted from g_begin) belongs to producer x & 1 and lives in stage x % NST; it is issued NST-1 chunks
+        // ahead.  A producer never has more than one chunk in flight, so "my chunk has landed" is a plain vmcnt(0).
+        const int D = U(a.NST - 1), nchunks = U(g_end - g_begin), g0 = U(g_begin);
+        auto stage_of = [&](int x) __attribute__((always_inline)) { return D == 1 ? (x & 1) : x % 3; };
+        if DVF_DBG(a, 8) return;
+        // the weights of the first chunks do not need the per-lane patch offsets: they go out before those are computed
+        for (int x = 0; x < D; ++x)
+            if (x < nchunks && (x & 1) == par) issue_w(g0 + x, stage_of(x));
+
+        // per-lane source offset of every patch piece: offset inside one image plane + (image in the batch group) x (image
+        // stride of the segment the producer is in); bit 31 set (OOB) = outside the image / the batch -> reads 0.0f
+        unsigned pvf[PIPE_MAXNPI];
+        unsigned pbn4[PIPE_MAXNPI / 4];                    // image inside the block's batch group (8-bit fields)
+#pragma unroll
+        for (int q = 0; q < PIPE_MAXNPI / 4; ++q) pbn4[q] = 0u;
         {
             const int per_img = geo.PH * RS;
             const float inv_img = 1.0f / (float)per_img, inv_rs = 1.0f / (float)RS;
 #pragma unroll
             for (int kk = 0; kk < PIPE_MAXNPI; ++kk) {
-                pvoff[kk] = OOB;
-                pbn[kk] = 0;
-                if (kk < geo.NPI) {
-                    const int p = (kk << 6) + lane;
+                pvf[kk] = OOB;
+                if (kk < NPIu) {
+                    // first float of this lane in piece kk: a piece is 64 lanes x 1 float, or 64 lanes x 4 floats (x4)
+                    const int p = a.x4 ? (((kk << 6) + lane) << 2) : ((kk << 6) + lane);
                     // exact small-integer division through fp32 (p < 2^16): estimate, then one correction step
                     int bn = (int)((float)p * inv_img);
                     bn += (p - bn * per_img >= per_img) - (p - bn * per_img < 0);
@@ -158,87 +239,127 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
                     int row = (int)((float)rem * inv_rs);
                     row += (rem - row * RS >= RS) - (rem - row * RS < 0);
                     const int col = rem - row * RS;
-                    int cs = col;
+                    int cs = col - geo.XA;                 // x4: image order, XA floats of aligned left margin
                     bool ok = (bn < a.BN) && (n0 + bn < a.N);
-                    if (a.IS == 2) {
+                    if (a.IS == 2 && !a.x4) {
                         cs = col < PWH ? 2 * col : 2 * (col - PWH) + 1;
                         ok = ok && (col < 2 * PWH);
                     }
-                    ok = ok && (cs < geo.PW);
+                    if (!a.x4) ok = ok && (cs < geo.PW);
                     const int iy = iy0 + row, ix = ix0 + cs;
                     ok = ok && (iy >= 0) && (iy < a.IH) && (ix >= 0) && (ix < a.IW);
-                    pvoff[kk] = ok ? (unsigned)((iy * a.IW + ix) << 2) : OOB;
-                    pbn[kk] = ok ? bn : 0;
+                    pvf[kk] = ok ? (unsigned)((iy * a.IW + ix) << 2) : OOB;
+                    pbn4[kk >> 2] |= (ok ? (unsigned)bn : 0u) << ((kk & 3) * 8);
                 }
             }
         }
-        const __amdgpu_buffer_rsrc_t rs_w = tensor_rsrc(a.wp);
-        unsigned voob = OOB;
-        asm volatile("" : "+v"(voob));                     // keep the constant in a VGPR (no per-use v_mov)
-        int iseg = 0, iseg_first = 0;
-        auto issue = [&](int g, int st) {
-            while (true) {
-                const int nchs = (a.segC[iseg] + CK - 1) / CK;
-                if (g < iseg_first + nchs) break;
-                iseg_first += nchs;
+        // a descriptor with zero records: every lane of a load through it is out of range and writes 0.0f -- the zero
+        // fill of a segment's channel tail, with the instruction stream of a real channel
+        const __amdgpu_buffer_rsrc_t rs_zero = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.wp), 0, 0, 0x00020000);
+        const unsigned plane = (unsigned)U((a.IH * a.IW) << 2);
+        // state of the segment the producer is in
+        int iseg = -1, iseg_first = 0, iseg_end = 0, segc = 0;       // chunks [iseg_first, iseg_end) belong to segment iseg
+        __amdgpu_buffer_rsrc_t rs_in = rs_zero;
+        unsigned img_cur = 0u;                             // image stride (bytes) already inside pvf
+        auto enter_segment = [&](int g) __attribute__((always_inline)) {
+            while (g >= iseg_end) {
                 ++iseg;
+                iseg_first = iseg_end;
+                iseg_end += (a.segC[iseg] + CK - 1) / CK;
             }
-            float *wl = smem + st * stage_floats;
-            float *patch = wl + a.SLmax;
-            if (!DVF_DBG(a, 2)) {
-                const unsigned slab = (c.wp_off + (unsigned)(mb * a.NCH + g) * (unsigned)c.SL) << 2;
-                for (int p = half; p < NWP; p += nhalf)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)(wl + (p << 8)), 16, (unsigned)lane << 4,
-                                                             slab + ((unsigned)p << 10), 0, 0);
+            iseg = U(iseg); iseg_first = U(iseg_first); iseg_end = U(iseg_end);
+            segc = U(a.segC[iseg]);
+            rs_in = tensor_rsrc(a.in[iseg]);
+            const unsigned img = (unsigned)segc * plane;
+            if (a.BN > 1) {                                // (valid offsets stay below 2^31: bit 31 keeps marking OOB lanes)
+                const unsigned delta = img - img_cur;
+#pragma unroll
+                for (int kk = 0; kk < PIPE_MAXNPI; ++kk)
+                    if (kk < NPIu) pvf[kk] = (pvf[kk] >> 31) ? OOB : pvf[kk] + ((pbn4[kk >> 2] >> ((kk & 3) * 8)) & 255u) * delta;
             }
-            if (!DVF_DBG(a, 1)) {
-                const int segc = a.segC[iseg];
-                const int c0 = (g - iseg_first) * CK;
-                const int nch = min(CK, segc - c0);
-                const __amdgpu_buffer_rsrc_t rs_in = tensor_rsrc(a.in[iseg]);
-                const unsigned plane = (unsigned)(a.IH * a.IW) << 2;
-                const unsigned img = (unsigned)segc * plane;
-                const unsigned cb = (unsigned)(n0 * segc + c0) * plane;
-                // (no vector ALU work per piece: a VALU instruction costs the MFMA wave sharing this SIMD 6-8 cycles)
-                for (int ci = half; ci < CK; ci += nhalf) {
-                    float *dst = patch + ci * PSR;
-                    if (ci >= nch) {                       // channel tail of the segment: zero-fill
+            img_cur = img;
+        };
+        // patch pieces of chunk g: NP = compile-time piece count (exact, or a bucket bound with a run-time guard)
+        auto issue_p = [&](int g, int st, auto lanec, auto npc, auto exactc) __attribute__((always_inline)) {
+            constexpr int LB = decltype(lanec)::value, NP = decltype(npc)::value;
+            constexpr bool EXACT = decltype(exactc)::value;
+            constexpr int PSH = LB == 16 ? 8 : 6;          // log2 floats per piece
+            if (g >= iseg_end) enter_segment(g);
+            const int c0 = U((g - iseg_first) * CK);
+            const int nch = U(min(CK, segc - c0));
+            float *dst = smem + st * sfl + SLmaxu + half * PSRu;
+            unsigned soff = (unsigned)U((int)((unsigned)(n0 * segc + c0 + half) * plane));
+            auto dma = [&](__amdgpu_buffer_rsrc_t r, float *d, unsigned vo, unsigned so) __attribute__((always_inline)) {
+                if constexpr (LB == 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)d, 16, vo, so, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)d, 4, vo, so, 0, 0);
+            };
+            int ci = half;
+            if (DVF_DBG(a, 32)) {                          // (ablation: same instructions, a linear L2-hot source)
+                for (; ci < nch; ci += nhalf) {
 #pragma unroll
-                        for (int kk = 0; kk < PIPE_MAXNPI; ++kk)
-                            if (kk < geo.NPI)
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(dst + (kk << 6)), 4, voob, 0u, 0, 0);
-                    } else if (a.BN > 1) {
-                        const unsigned soff = cb + (unsigned)ci * plane;
-#pragma unroll
-                        for (int kk = 0; kk < PIPE_MAXNPI; ++kk)
-                            if (kk < geo.NPI) {
-                                const unsigned vo = (pvoff[kk] == OOB) ? OOB : pvoff[kk] + (unsigned)pbn[kk] * img;
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(dst + (kk << 6)), 4, vo, soff, 0, 0);
-                            }
-                    } else {
-                        const unsigned soff = cb + (unsigned)ci * plane;
-#pragma unroll
-                        for (int kk = 0; kk < PIPE_MAXNPI; ++kk)
-                            if (kk < geo.NPI)
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(dst + (kk << 6)), 4, pvoff[kk], soff, 0, 0);
-                    }
+                    for (int kk = 0; kk < NP; ++kk)
+                        if (EXACT || kk < NPIu) dma(rs_in, dst + (kk << PSH), (unsigned)lane * LB, (unsigned)(kk << (PSH + 2)));
+                    dst += nhalf * PSRu;
                 }
             }
+            for (; ci < nch; ci += nhalf) {
+#pragma unroll
+                for (int kk = 0; kk < NP; ++kk)
+                    if (EXACT || kk < NPIu) dma(rs_in, dst + (kk << PSH), pvf[kk], soff);
+                dst += nhalf * PSRu;
+                soff += (unsigned)nhalf * plane;
+            }
+            for (; ci < CK; ci += nhalf) {                 // channel tail of the segment: zeros
+#pragma unroll
+                for (int kk = 0; kk < NP; ++kk)
+                    if (EXACT || kk < NPIu) dma(rs_zero, dst + (kk << PSH), pvf[kk], 0u);
+                dst += nhalf * PSRu;
+            }
         };
-        if DVF_DBG(a, 8) return;
-        // Chunk x (counted from g_begin) belongs to producer x & 1 and lives in stage x % NST; it is issued NST-1 chunks
-        // ahead.  A producer never has more than one chunk in flight, so "my chunk has landed" is a plain vmcnt(0).
-        const int D = a.NST - 1, nchunks = g_end - g_begin;
-        auto stage_of = [&](int x) { return a.NST == 2 ? (x & 1) : x % 3; };
-        for (int x = 0; x < D; ++x)
-            if (x < nchunks && (x & 1) == par) issue(g_begin + x, stage_of(x));
-        for (int x = 0; x < nchunks; ++x) {
-            // chunk x must have landed before anyone passes this barrier; chunk x-1 is fully consumed after it, which
-            // frees the stage chunk x+D goes to
-            if ((x & 1) == par) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const int nx = x + D;
-            if (nx < nchunks && (nx & 1) == par) issue(g_begin + nx, stage_of(nx));
+        using std::integral_constant;
+        unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, w_vm = 0, w_bar = 0, w_iss = 0;
+        // The chunk loop is instantiated per (lane width, piece count): the dispatch runs ONCE per block, and what a producer
+        // executes per chunk is one short contiguous stretch of code (a per-chunk switch over the variants cost 2.6 us per
+        // call on the cycle account -- far-apart code, instruction fetches -- for four DMA instructions).
+        auto chunk_loop = [&](auto lanec, auto npc, auto exactc) __attribute__((always_inline)) {
+            if (!DVF_DBG(a, 1))
+                for (int x = 0; x < D; ++x)
+                    if (x < nchunks && (x & 1) == par) issue_p(g0 + x, stage_of(x), lanec, npc, exactc);
+            for (int x = 0; x < nchunks; ++x) {
+                // chunk x must have landed before anyone passes this barrier; chunk x-1 is fully consumed after it, which
+                // frees the stage chunk x+D goes to
+                DVF_STAMP(a, p0);
+                if ((x & 1) == par) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                DVF_STAMP(a, p1);
+                __builtin_amdgcn_s_barrier();
+                DVF_STAMP(a, p2);
+                const int nx = x + D;
+                if (nx < nchunks && (nx & 1) == par) {
+                    issue_w(g0 + nx, stage_of(nx));
+                    if (!DVF_DBG(a, 1)) issue_p(g0 + nx, stage_of(nx), lanec, npc, exactc);
+                }
+                DVF_STAMP(a, p3);
+                w_vm += p1 - p0; w_bar += p2 - p1; w_iss += p3 - p2;
+            }
+        };
+        auto by_np = [&](auto lanec) __attribute__((always_inline)) {
+            switch (NPIu) {
+                case 1: chunk_loop(lanec, integral_constant<int, 1>{}, std::true_type{}); break;
+                case 2: chunk_loop(lanec, integral_constant<int, 2>{}, std::true_type{}); break;
+                case 3: chunk_loop(lanec, integral_constant<int, 3>{}, std::true_type{}); break;
+                case 4: chunk_loop(lanec, integral_constant<int, 4>{}, std::true_type{}); break;
+                case 5: chunk_loop(lanec, integral_constant<int, 5>{}, std::true_type{}); break;
+                case 6: chunk_loop(lanec, integral_constant<int, 6>{}, std::true_type{}); break;
+                default:
+                    if (NPIu <= 12) chunk_loop(lanec, integral_constant<int, 12>{}, std::false_type{});
+                    else chunk_loop(lanec, integral_constant<int, PIPE_MAXNPI>{}, std::false_type{});
+            }
+        };
+        if (a.x4) by_np(integral_constant<int, 16>{});
+        else by_np(integral_constant<int, 4>{});
+        if (DVF_STAMPS_ON && a.stamps && pidx == 0 && lane == 0) {
+            a.stamps[8 * lin_block + 5] = w_vm; a.stamps[8 * lin_block + 6] = w_bar; a.stamps[8 * lin_block + 7] = w_iss;
         }
         return;
     }
@@ -263,7 +384,8 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
         opy[i] = ty * SH + pyl;
         opx[i] = tx * SW + pxl;
         opn[i] = tn * SN + pnl;
-        const int bbase = kh * PSR + (opn[i] * geo.PH + opy[i] * a.IS) * RS + opx[i];
+        // x4: rows in image order behind XA floats of margin (stride-2 tiles read every other float)
+        const int bbase = kh * PSR + (opn[i] * geo.PH + opy[i] * a.IS) * RS + (a.x4 ? geo.XA + opx[i] * a.IS : opx[i]);
 #pragma unroll
         for (int j = 0; j < VW; ++j) bj[i][j] = bbase + j * 2 * PSR;
     }
@@ -390,20 +512,39 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
         }
     };
 
+    unsigned long long t_loop0 = 0, t_loop1 = 0, tb0 = 0, tb1 = 0, w_bar = 0;
+    DVF_STAMP(a, t_loop0);
     if (!DVF_DBG(a, 8)) {
         int st = 0;
         for (int g = g_begin; g < g_end; ++g) {
+            DVF_STAMP(a, tb0);
             __syncthreads();          // chunk g has landed (its producer waited for it) and chunk g-1 is fully consumed
+            DVF_STAMP(a, tb1);
+            w_bar += tb1 - tb0;
             if (!DVF_DBG(a, 4)) {
-                if (a.IS == 2) consume(st, std::integral_constant<int, 2>{});
+                if (a.IS == 2 && !a.x4) consume(st, std::integral_constant<int, 2>{});      // (de-interleaved rows)
                 else consume(st, std::integral_constant<int, 1>{});
             }
             st = (st + 1 == a.NST) ? 0 : st + 1;
         }
     }
 
+    DVF_STAMP(a, t_loop1);
+    // (tuning build) the account is written when the wave leaves the kernel: epilogue stores issued AND completed
+    auto stamp_out = [&]() {
+        if (DVF_STAMPS_ON && a.stamps && wave == 0) {
+            unsigned long long t_end = 0, r_end = 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DVF_STAMP(a, t_end);
+            DVF_STAMP_RT(a, r_end);
+            if (lane == 0) {
+                unsigned long long *o = a.stamps + 8 * lin_block;
+                o[0] = t_loop0 - t_entry; o[1] = t_loop1 - t_loop0; o[2] = w_bar; o[3] = t_end - t_loop1; o[4] = r_end - r_entry;
+            }
+        }
+    };
     // ---- epilogue: D[row = channel][col = pixel]; lanes 0-31 / 32-63 hold channel rows +0 / +4
-    if DVF_DBG(a, 16) return;
+    if DVF_DBG(a, 16) { stamp_out(); return; }
     const int m0 = mb * (32 * MTW) + wm * (32 * MT);
     float *outp = a.out + (a.out_mode == 2 ? (int64_t)ks * a.ws_slice : 0);
     const int64_t HW = (int64_t)a.OH * a.OW;
@@ -455,6 +596,7 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
                     if (nl == 0 && mm < a.M) atomicAdd(a.dbias + mm, sv);
                 }
         }
+        stamp_out();
         return;
     }
     // The output mode, the activation and "every channel of this wave exists" are launch constants: the store loops are
@@ -512,6 +654,7 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
     else if (a.act == DVF_ACT_RELU) by_full(integral_constant<int, 0>{}, integral_constant<int, DVF_ACT_RELU>{});
     else if (a.act == DVF_ACT_SIGMOID_AFFINE) by_full(integral_constant<int, 0>{}, integral_constant<int, DVF_ACT_SIGMOID_AFFINE>{});
     else by_full(integral_constant<int, 0>{}, integral_constant<int, DVF_ACT_NONE>{});
+    stamp_out();
 }
 
 // Launch one (MT, NT, WM) family; CKH in {2,4,8} and TBU in {2,3,4} are dispatched inside.  Defined in the

@@ -193,6 +193,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_mask_kernel(const float *ws
     if (threadIdx.x == 0) atomicAdd(dbias + plane % C, red[0] + red[1] + red[2] + red[3]);
 }
 
+#ifdef DVF_TUNING
+constexpr size_t STAMP_MAX_BLOCKS = 16384;
+unsigned long long *g_stamp_buf = nullptr;
+int g_stamp_blocks = 0;
+#endif
 // ---------------------------------------------------------------------------------------- host planning
 struct PipePlan {
     int MT, NT, WM, CKH, TBU, threads;
@@ -305,38 +310,53 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     a.BW = tp.TGX << tp.lsw; a.BH = tp.TGY << tp.lsh;
     a.tilesX = cdiv(OWc, a.BW); a.tilesY = cdiv(OHc, a.BH); a.NG = cdiv(a.N, a.BN);
     const int SW = 1 << a.lsw, SH = 1 << a.lsh, MB = 32 * MT * WM;
-    int PSRmax = 0;
-    for (int i = 0; i < ncls; ++i) {
-        const PipeGeo g = pipe_geo(a.BH, a.BW, a.BN, a.IS, cls[i].TA, TBU, SW, SH);
-        if (g.NPI > PIPE_MAXNPI) return DVF_ERR_UNSUPPORTED;
-        PSRmax = g.PSR > PSRmax ? g.PSR : PSRmax;
-    }
-    a.PSRmax = PSRmax;
-    // --- chunk depth: largest CK in {16,8,4} whose two stages fit the LDS budget
+    // patch DMA in 16-byte lanes (pipe_geo): image rows and tile origins must be 16-byte aligned (the tensor base pointers
+    // are checked at launch, pipe_run).  The wider rows cost LDS: where they would push the chunk depth below what 4-byte
+    // lanes allow, the deeper chunks win (profiles/r03_pipe_stamps_after.txt: 3x3 128->128 @32x104, CK 16 vs 8).
     auto slab = [&](int CK, int TA) { return (TA * TBU * CK * MB + 255) & ~255; };
-    int NST = 3;
-    auto lds_bytes = [&](int CK) { return ((size_t)NST * (slab(CK, TAmax) + (size_t)CK * PSRmax) + MB) * 4; };
-    // LDS budget: a grid of at most one block per CU may take (nearly) the whole 160 KiB; otherwise leave room for two
     static const int ks_thr = dvf_tune("DVF_PIPE_KSTHR") ? atoi(dvf_tune("DVF_PIPE_KSTHR")) : 160;       // tuning knobs
     static const int ks_tgt = dvf_tune("DVF_PIPE_KSTGT") ? atoi(dvf_tune("DVF_PIPE_KSTGT")) : 256;
     const int KS0 = nblk < ks_thr ? (int)(ks_tgt / nblk) : 1;     // split-K factor before clamping to the chunk count
     static const int big_lds_kb = dvf_tune("DVF_PIPE_BIGLDS_KB") ? atoi(dvf_tune("DVF_PIPE_BIGLDS_KB")) : 150;   // tuning knob
+    // LDS budget: a grid of at most one block per CU may take (nearly) the whole 160 KiB; otherwise leave room for two
     const size_t PIPE_LDS_BUDGET = (nblk * KS0 <= 256 ? big_lds_kb : 76) * 1024;
-    int CK = TBU >= 5 ? 8 : 16;                          // (the 5- and 7-tap kernels are only built for CK <= 8)
-    while (CK > 4 && lds_bytes(CK) > PIPE_LDS_BUDGET) CK >>= 1;
-    while (CK > 4 && CK / 2 >= maxc) CK >>= 1;
-    if (lds_bytes(CK) > PIPE_LDS_BUDGET) {                   // large kernels (5x5, 7x7): two stages, then one block per CU
-        NST = 2;
-        if (lds_bytes(CK) > PIPE_LDS_BUDGET && PIPE_LDS_BUDGET < 150 * 1024) {
-            NST = 3;
-            if (lds_bytes(CK) > 150 * 1024) NST = 2;
-            if (lds_bytes(CK) > 150 * 1024) return DVF_ERR_UNSUPPORTED;
+    struct Depth { int ok, CK, NST, PSRmax; size_t lds; };
+    auto depth_for = [&](int x4) {
+        Depth d{0, 0, 3, 0, 0};
+        for (int i = 0; i < ncls; ++i) {
+            const PipeGeo g = pipe_geo(a.BH, a.BW, a.BN, a.IS, cls[i].TA, TBU, SW, SH, x4, cls[i].bx);
+            if (g.NPI > PIPE_MAXNPI) return d;
+            d.PSRmax = g.PSR > d.PSRmax ? g.PSR : d.PSRmax;
         }
-    }
-    if (ov.on && ov.CK) { CK = ov.CK; NST = 3; if (lds_bytes(CK) > 150 * 1024) NST = 2; }
-    if (ov.on && ov.NST) NST = ov.NST;
-    if (CK != 4 && CK != 8 && CK != 16) return DVF_ERR_UNSUPPORTED;
-    if (lds_bytes(CK) > 150 * 1024) return DVF_ERR_UNSUPPORTED;
+        auto lds_bytes = [&](int CK) { return ((size_t)d.NST * (slab(CK, TAmax) + (size_t)CK * d.PSRmax) + MB) * 4; };
+        // chunk depth: largest CK in {16,8,4} whose stages fit the LDS budget
+        int CK = TBU >= 5 ? 8 : 16;                          // (the 5- and 7-tap kernels are only built for CK <= 8)
+        while (CK > 4 && lds_bytes(CK) > PIPE_LDS_BUDGET) CK >>= 1;
+        while (CK > 4 && CK / 2 >= maxc) CK >>= 1;
+        if (lds_bytes(CK) > PIPE_LDS_BUDGET) {               // large kernels (5x5, 7x7): two stages, then one block per CU
+            d.NST = 2;
+            if (lds_bytes(CK) > PIPE_LDS_BUDGET && PIPE_LDS_BUDGET < 150 * 1024) {
+                d.NST = 3;
+                if (lds_bytes(CK) > 150 * 1024) d.NST = 2;
+                if (lds_bytes(CK) > 150 * 1024) return d;
+            }
+        }
+        if (ov.on && ov.CK) { CK = ov.CK; d.NST = 3; if (lds_bytes(CK) > 150 * 1024) d.NST = 2; }
+        if (ov.on && ov.NST) d.NST = ov.NST;
+        if ((CK != 4 && CK != 8 && CK != 16) || lds_bytes(CK) > 150 * 1024) return d;
+        d.ok = 1; d.CK = CK; d.lds = lds_bytes(CK);
+        return d;
+    };
+    int want_x4 = (a.IW % 4 == 0 && (a.BW * a.IS) % 4 == 0) ? 1 : 0;
+    if (const char *e = dvf_tune("DVF_PIPE_X4")) want_x4 = want_x4 && atoi(e) != 0;    // tuning knob: 0 = 4-byte lanes everywhere
+    const Depth d1 = depth_for(0), d4 = want_x4 ? depth_for(1) : Depth{0, 0, 3, 0, 0};
+    static const bool x4_force = dvf_tune("DVF_PIPE_X4") && atoi(dvf_tune("DVF_PIPE_X4")) == 2;           // tuning: 2 = whenever legal
+    const bool use4 = d4.ok && (!d1.ok || x4_force || (d4.CK >= d1.CK && d4.NST >= d1.NST));
+    const Depth dd = use4 ? d4 : d1;
+    if (!dd.ok) return DVF_ERR_UNSUPPORTED;
+    a.x4 = use4 ? 1 : 0;
+    a.PSRmax = dd.PSRmax;
+    const int CK = dd.CK, NST = dd.NST;
     a.NST = NST;
     a.SLmax = slab(CK, TAmax);
     a.NCH = 0;
@@ -362,7 +382,7 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     pl.ws_floats = KS > 1 ? (int64_t)KS * a.N * a.M * a.OH * a.OW : 0;
     for (int s2 = 0; s2 < a.nseg; ++s2)
         if ((int64_t)a.N * a.segC[s2] * a.IH * a.IW * 4 >= ((int64_t)1 << 31) - 16) return DVF_ERR_UNSUPPORTED;
-    pl.MT = MT; pl.NT = NT; pl.WM = WM; pl.CKH = CK / 2; pl.TBU = TBU; pl.lds = lds_bytes(CK);
+    pl.MT = MT; pl.NT = NT; pl.WM = WM; pl.CKH = CK / 2; pl.TBU = TBU; pl.lds = dd.lds;
     pl.grid = dim3(a.tilesX * a.tilesY, mblocks, a.NG * KS * ncls);
     // a block that has a CU to itself (by LDS size or by grid size) gets four producer waves, one per SIMD
     {
@@ -414,7 +434,22 @@ int pipe_run(PipeOp &op, const float *packed, float *ws, int64_t ws_floats, hipS
     a.out_mode = mode;
     if (mode == 2) { a.out = ws; a.ws_slice = total; }
     if (const char *e = dvf_tune("DVF_DBG")) a.dbg = atoi(e);
-    dvf_plan_note(DVF_K_PIPE, pl.MT, pl.NT, pl.WM, 2 * pl.CKH, pl.TBU, a.KS, a.BN, a.NST, pl.threads, (int)pl.lds, mode | (a.ncls << 4));
+    a.stamps = nullptr;
+#ifdef DVF_TUNING
+    if (dvf_tune("DVF_STAMPS")) {      // in-kernel cycle account of the LAST pipelined launch (tools/r3/stamps.py)
+        const size_t nb = (size_t)pl.grid.x * pl.grid.y * pl.grid.z;
+        if (!g_stamp_buf && hipMalloc(&g_stamp_buf, STAMP_MAX_BLOCKS * 64) != hipSuccess) return DVF_ERR_LAUNCH;
+        if (nb <= STAMP_MAX_BLOCKS) {
+            if (hipMemsetAsync(g_stamp_buf, 0, nb * 64, st) != hipSuccess) return DVF_ERR_LAUNCH;
+            a.stamps = g_stamp_buf;
+            g_stamp_blocks = (int)nb;
+        }
+    }
+#endif
+    if (a.x4)
+        for (int s2 = 0; s2 < a.nseg; ++s2)
+            if (reinterpret_cast<uintptr_t>(a.in[s2]) & 15) return DVF_ERR_UNSUPPORTED;    // (a view at an odd element offset)
+    dvf_plan_note(DVF_K_PIPE, pl.MT, pl.NT, pl.WM, 2 * pl.CKH, pl.TBU, a.KS, a.BN, a.NST, pl.threads, (int)pl.lds, mode | (a.ncls << 4) | (a.x4 << 8));
     if (dvf_tune("DVF_PIPE_DEBUG"))
         fprintf(stderr, "[pipe] M %d chunks %d N %d out %dx%d cls %d | MT %d NT %d WM %d CK %d TBU %d KS %d BN %d tile %dx%d "
                 "(sub %dx%d) grid %ux%ux%u lds %zu x%d mode %d\n", a.M, a.NCH, a.N, a.OH, a.OW, a.ncls, pl.MT, pl.NT, pl.WM,

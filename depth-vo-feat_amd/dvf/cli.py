@@ -24,6 +24,10 @@ def add_common_flags(parser):
     g.add_argument("--width", type=int, default=832)
     g.add_argument("--steps-per-epoch", type=int, default=50, help="synthetic iterations per epoch")
     g.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    g.add_argument("--reference-stereo-pose", action="store_true",
+                   help="feed the dataset's T_R2L file vector (0,0,0,Tx,0,0) unchanged into pose_vec2mat / the stereo-pose "
+                        "MSE target, exactly as the reference does (unsupervise.py:101, train.py:201); default: convert it "
+                        "to the (t, r-euler) order those functions read (un_dataset.to_batch)")
 
 
 def init_distributed():
@@ -96,7 +100,7 @@ def run_training(args, nets, loss_fn, lr, betas, weight_decay, term_names, ckpt_
         def feed():
             while True:
                 for sample in loader:
-                    yield un_dataset.to_batch(sample, device)
+                    yield un_dataset.to_batch(sample, device, getattr(args, "reference_stereo_pose", False))
         feed = feed()
     KEYS = ("img_R2", "img_R1", "img_L2", "K", "Kinv", "T_R2L", "T_R2L_se3")
 

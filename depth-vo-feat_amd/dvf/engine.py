@@ -63,6 +63,8 @@ class FlatAdam:
             p._dvf_offset = o
             p._dvf_touched = False
             p._dvf_owner = self
+            p._dvf_calls = 0          # grad_ready() calls of the current step ...
+            p._dvf_expect = 0         # ... and how many a step makes (learnt from the previous steps)
         # gradient buckets = contiguous arena slices of ~bucket_mb, in backward order
         self.buckets, cur_start, cur_params = [], 0, []
         limit = int(bucket_mb * 1024 * 1024 / 4)
@@ -83,6 +85,7 @@ class FlatAdam:
         self._main_stream = None     # compute stream of the step (recorded by zero_grad)
         self.n_reduced = 0           # buckets exchanged so far (tests / bench bookkeeping)
         self._ranges = None
+        self._stable = False
         self._reset_pending()
         self.side = torch.cuda.Stream(device=dev) if (wgrad_stream and dev.type == "cuda") else None
         self._sides = {}         # compute stream -> its weight-gradient stream (the main stream's is self.side)
@@ -125,24 +128,54 @@ class FlatAdam:
 
     # ------------------------------------------------------------------ autograd side (called from ConvFn.backward)
     def _reset_pending(self):
+        """Start of a step.  A bucket may leave from inside backward only when the LAST gradient contribution of every
+        parameter in it has been enqueued.  A parameter receives one grad_ready() call per use of its module in the step
+        (a network applied to two images calls twice: shared weights), so the engine learns the number of calls per
+        parameter from the step before and launches a bucket when every touched parameter has reached its count.  The
+        first step (counts unknown) runs without early launches: ``step()`` exchanges and updates everything.  A step that
+        makes FEWER calls than the previous one simply leaves the affected buckets to ``step()``; one that makes MORE is
+        caught in grad_ready()."""
+        stable = self._ranges is not None
+        for p in self.params:
+            if p._dvf_expect < 0:     # relearn(): one step without early launches
+                stable = False
+            p._dvf_expect = p._dvf_calls
+            p._dvf_calls = 0
+        self._stable = stable
         for b in self.buckets:
-            b["pending"] = sum(1 for p in b["params"] if p._dvf_touched or self._ranges is None)
+            b["pending"] = sum(p._dvf_expect for p in b["params"]) if stable else -1      # -1: no early launch this step
             b["launched"] = False
             b["updated"] = False
         self._adam_started = False
 
     def grad_ready(self, p):
-        """A weight/bias gradient has been enqueued on the compute stream."""
+        """A weight/bias gradient contribution has been enqueued on the compute stream."""
         if not p._dvf_touched:
             p._dvf_touched = True
             p.grad = p._dvf_grad            # expose it the torch way
             self._ranges = None
+        p._dvf_calls += 1
         if not ((self.exchange or self.early_update) and self.overlap):
             return
         b = self.buckets[p._dvf_bucket]
+        if b["launched"]:
+            # its bucket has already been exchanged / updated: this contribution would be lost (and the remaining dgrads
+            # of the step would read updated weights).  Only possible when the step's graph changed under the engine.
+            raise RuntimeError("FlatAdam: a gradient of a parameter arrived after its bucket had left (the step uses a module "
+                               "more often than the previous step did); run this step with early launches disabled "
+                               "(FlatAdam.relearn()) or construct the optimizer with overlap=False")
+        if b["pending"] < 0 or p._dvf_calls > p._dvf_expect:
+            b["pending"] = -1               # unexpected call pattern: leave this bucket to step()
+            return
         b["pending"] -= 1
-        if b["pending"] <= 0 and not b["launched"] and self._ranges is not None:
+        if b["pending"] == 0 and self._ranges is not None:
             self._launch_bucket(b)
+
+    def relearn(self):
+        """Forget the learnt call counts: the next step runs without early launches and re-learns them (call this when
+        the step function changes, e.g. a network starts being applied a second time)."""
+        for p in self.params:
+            p._dvf_expect = -1
 
     def _bucket_ranges(self, b):
         """Contiguous arena ranges of the bucket's parameters that received a gradient."""
@@ -283,4 +316,9 @@ class GraphedStep:
             if src is not None and src is not dst:
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        # The replay updated the weights through raw pointers and refreshed the packed copies that existed at capture time;
+        # no Python bookkeeping ran.  Bump the manual epoch so that every packed copy is re-validated (and repacked) the next
+        # time EAGER code uses it -- e.g. validate() between replays with a batch size the capture never saw: its packed
+        # copy would otherwise keep a matching stamp and serve the weights of the epoch it was first built in.
+        L.PACK_EPOCH += 1
         return self.outputs

@@ -127,14 +127,22 @@ def se3_to_tr_euler(se3):
     return torch.cat((t, torch.stack((rx, ry, rz), dim=1)), dim=1).to(se3.dtype)
 
 
-def to_batch(sample_batch, device):
+def to_batch(sample_batch, device, reference_stereo_pose=False):
     """Collated dataset output -> the batch dict of dvf/steps.py (device tensors).  The stereo pose is provided in BOTH
-    conventions: ``T_R2L_se3`` as the files hold it (w, u) for unsupervise_dvo.py, and ``T_R2L`` converted to the
-    (t, r-euler) order of pose_vec2mat for unsupervise.py / train.py -- the two APIs must never see each other's."""
+    conventions: ``T_R2L_se3`` as the files hold it (w, u) for unsupervise_dvo.py, and ``T_R2L`` for unsupervise.py /
+    train.py, whose pose_vec2mat wants (t, r-euler).
+
+    DELIBERATE DEPARTURE FROM THE REFERENCE (default): the reference feeds the file vector (0, 0, 0, Tx, 0, 0) UNCHANGED
+    into pose_vec2mat (unsupervise.py:101) and into the stereo-pose target F.mse_loss(pose[:,1], T_R2L) (train.py:184,201),
+    where it means "no translation, a rotation of Tx radians about x" (SURVEY preamble #6) -- not the stereo rig.  By
+    default this build converts the vector to (Tx, 0, 0, 0, 0, 0); ``reference_stereo_pose=True`` (the entry scripts'
+    ``--reference-stereo-pose``) passes the file vector through exactly as the reference does, for runs that must reproduce
+    the reference's numbers on real data (pinned by tests/golden/photo_c3_32x104_rawpose.npz)."""
     r1, l2, r2, K, Kinv, raw_K, T = [x.to(device, non_blocking=True) for x in sample_batch]
     se3 = T.reshape(T.shape[0], -1)[:, :6].contiguous()
+    tr = se3 if reference_stereo_pose else se3_to_tr_euler(se3).contiguous()
     return {"img_R1": r1.contiguous(), "img_L2": l2.contiguous(), "img_R2": r2.contiguous(), "K": K.contiguous(),
-            "Kinv": Kinv.contiguous(), "raw_K": raw_K, "T_R2L_se3": se3, "T_R2L": se3_to_tr_euler(se3).contiguous()}
+            "Kinv": Kinv.contiguous(), "raw_K": raw_K, "T_R2L_se3": se3, "T_R2L": tr}
 
 
 def collate_raw(samples):
@@ -144,8 +152,8 @@ def collate_raw(samples):
     return [list(cols[0]), list(cols[1]), list(cols[2])] + [torch.stack(c) for c in cols[3:]]
 
 
-def to_batch_raw(raw_batch, device, size):
+def to_batch_raw(raw_batch, device, size, reference_stereo_pose=False):
     """``collate_raw`` output -> the batch dict, with the reference's per-frame imresize done on the GPU."""
     from dvf.image_ops import gpu_imresize
     frames = [torch.stack([gpu_imresize(f.to(device, non_blocking=True), size) for f in col]) for col in raw_batch[:3]]
-    return to_batch(frames + list(raw_batch[3:]), device)
+    return to_batch(frames + list(raw_batch[3:]), device, reference_stereo_pose)

@@ -150,6 +150,29 @@ def gen_losses():
          **{f"g_depth{s}": _np(depth[s].grad) for s in range(4)})
 
 
+def gen_stereo_pose():
+    """The stereo pose AS THE REFERENCE'S DATASET HOLDS IT, (0, 0, 0, Tx, 0, 0) (data/dataset_builder.py:155), fed unchanged
+    into loss_functions.photometric_reconstruction_loss -- which is what unsupervise.py:101 / train.py:201 do with real data
+    (SURVEY preamble #6): pose_vec2mat reads it as zero translation and a rotation of Tx radians about x.  Pins the
+    `--reference-stereo-pose` mode of the entry scripts (un_dataset.to_batch(reference_stereo_pose=True))."""
+    import loss_functions as ref_lf
+    b, c, h, w = 2, 3, 32, 104
+    g = torch.Generator().manual_seed(77)
+    mk = lambda: torch.rand(b, c, h, w, generator=g, dtype=torch.float64).float()
+    R2, R1, L2 = mk(), mk(), mk()
+    depth = (torch.rand(b, h, w, generator=g, dtype=torch.float64) * 29 + 1).float()
+    T21 = (torch.randn(b, 6, generator=g, dtype=torch.float64) * 0.05).float()
+    TRL = torch.tensor([0, 0, 0, -0.54, 0, 0], dtype=torch.float32).expand(b, 6).clone()
+    K, Kinv = kitti_K(b, h, w, torch.float32)
+    for t in (R2, R1, L2, depth, T21, TRL):
+        t.requires_grad_(True)
+    loss = ref_lf.photometric_reconstruction_loss(R2, R1, L2, depth, T21, TRL, K, Kinv)
+    loss.backward()
+    save("photo_c3_32x104_rawpose", R2=_np(R2), R1=_np(R1), L2=_np(L2), depth=_np(depth), T21=_np(T21),
+         TRL=_np(TRL), K=_np(K), Kinv=_np(Kinv), loss=_np(loss), g_R2=_np(R2.grad), g_R1=_np(R1.grad),
+         g_L2=_np(L2.grad), g_depth=_np(depth.grad), g_T21=_np(T21.grad), g_TRL=_np(TRL.grad))
+
+
 def grad_digest(named_grads):
     """Per-parameter (l2 norm, sum, first 8 elements) in fp64: small but sensitive."""
     keys = sorted(named_grads)
@@ -379,7 +402,7 @@ def main():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")      # grid_sample align_corners default-change warning
         groups = {"warp": gen_warp, "losses": gen_losses, "nets": gen_nets, "steps": gen_steps, "metrics": gen_metrics,
-                  "se3": gen_se3}
+                  "se3": gen_se3, "stereo": gen_stereo_pose}
         only = [a for a in sys.argv[1:] if a in groups]
         for name, fn in groups.items():          # usage: gen_golden.py [group ...]   (default: all)
             if not only or name in only:

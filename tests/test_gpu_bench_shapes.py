@@ -109,89 +109,107 @@ def _distinct(geoms):
     return out
 
 
+def _check_geometry(gi, geom, failures):
+    """Forward / dgrad / wgrad / bias-grad of one convolution geometry against torch CPU at 1e-4: plain, and in the fused
+    form the steps run (masked dgrad, weight gradient + bias column)."""
+    from dvf.conv import ConvFn, ReluTag
+    segs, cout, cfg, (n, h, w), need_in = geom
+    k, stride, pad, opad, transposed, act, alpha, beta, out_hw = cfg
+    gen = torch.Generator().manual_seed(1000 + gi)
+    cin = sum(segs)
+    xs = [torch.randn(n, c, h, w, generator=gen) for c in segs]
+    wshape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+    wt = torch.randn(wshape, generator=gen) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=gen) * 0.1
+    rx = [x.clone().requires_grad_(ng) for x, ng in zip(xs, need_in)]
+    rw, rb = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xin = torch.cat(rx, 1)
+    if transposed:
+        pre = F.conv_transpose2d(xin, rw, rb, stride=stride, padding=pad, output_padding=opad)
+    else:
+        pre = F.conv2d(xin, rw, rb, stride=stride, padding=pad)
+    if out_hw is not None:
+        pre = pre[:, :, :out_hw[0], :out_hw[1]]
+    ref = _ref_act(pre, act, alpha, beta)
+    gout = torch.randn(ref.shape, generator=gen)
+    if act == 1:
+        gout = gout * (pre.detach().abs() > 1e-4)       # ReLU kink: see test_gpu_conv.py
+    (ref * gout).sum().backward()
+    gx = [x.clone().to(DEV).requires_grad_(ng) for x, ng in zip(xs, need_in)]
+    gw, gb = wt.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+    out = ConvFn.apply(gw, gb, cfg, *gx)
+    (out * gout.to(DEV)).sum().backward()
+    tag = f"{'T' if transposed else 'C'}{k}x{k}s{stride} {list(segs)}->{cout} @{h}x{w} N{n}"
+    errs = {"fwd": rel_err(out, ref), "wgrad": rel_err(gw.grad, rw.grad), "bias": rel_err(gb.grad, rb.grad)}
+    for i, (a, r) in enumerate(zip(gx, rx)):
+        if r.grad is not None:
+            errs[f"dgrad{i}"] = rel_err(a.grad, r.grad)
+    bad = {kk: v for kk, v in errs.items() if not v < TOL}
+    if bad or tuple(out.shape) != tuple(ref.shape):
+        failures.append((tag, bad))
+    del out, gx, gw, gb, rx, rw, rb, ref, pre, gout
+    # ---- the same geometry as the step runs it (dvf/conv.py::ReluTag): inputs are outputs of ReLU layers, so the
+    # dgrad leaves multiplied by (x > 0); a ReLU layer itself receives dL/dpre (its consumers masked it) and its
+    # bias gradient is the extra column of the weight-gradient kernel (dvf_conv2d_wgrad_bias)
+    xs2 = [F.relu(x) for x in xs]
+    rx = [x.clone().requires_grad_(ng) for x, ng in zip(xs2, need_in)]
+    rw, rb = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xin = torch.cat(rx, 1)
+    if transposed:
+        pre = F.conv_transpose2d(xin, rw, rb, stride=stride, padding=pad, output_padding=opad)
+    else:
+        pre = F.conv2d(xin, rw, rb, stride=stride, padding=pad)
+    if out_hw is not None:
+        pre = pre[:, :, :out_hw[0], :out_hw[1]]
+    ref = _ref_act(pre, act, alpha, beta)
+    gout = torch.randn(ref.shape, generator=gen)
+    if act == 1:
+        gout = gout * (pre.detach().abs() > 1e-4)
+    (ref * gout).sum().backward()
+    gx = [x.clone().to(DEV).requires_grad_(ng) for x, ng in zip(xs2, need_in)]
+    for x in gx:
+        x._dvf_relu_tag = ReluTag()
+    gw, gb = wt.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+    out = ConvFn.apply(gw, gb, tuple(cfg) + ((ReluTag(),) if act == 1 else ()), *gx)
+    go = gout * (ref.detach() > 0) if act == 1 else gout        # what masking consumers deliver
+    out.backward(go.to(DEV))
+    errs = {"fused wgrad": rel_err(gw.grad, rw.grad), "fused bias": rel_err(gb.grad, rb.grad)}
+    for i, (a, r, x0) in enumerate(zip(gx, rx, xs2)):
+        if r.grad is not None:
+            errs[f"masked dgrad{i}"] = rel_err(a.grad, r.grad * (x0 > 0))
+    bad = {kk: v for kk, v in errs.items() if not v < TOL}
+    if bad:
+        failures.append((tag, bad))
+    del out, gx, gw, gb, rx, rw, rb, ref, pre, gout, go
+
+
+def _check_geometries(geoms, seed_base):
+    """Run the geometries not parity-checked yet (any configuration); their plan records join STATE['layer_plans']."""
+    from dvf import lib as L
+    done = STATE.setdefault("checked_geoms", set())
+    plans = STATE.setdefault("layer_plans", set())
+    L.PLAN_LOG = set()
+    failures = []
+    try:
+        for gi, geom in enumerate(geoms):
+            if geom in done:
+                continue
+            _check_geometry(seed_base + gi, geom, failures)
+            done.add(geom)
+            torch.cuda.empty_cache()
+    finally:
+        plans |= L.PLAN_LOG
+        L.PLAN_LOG = None
+    assert not failures, failures
+
+
 def test_every_bench_layer_geometry():
     """Forward / dgrad / wgrad / bias-grad of every distinct convolution geometry of the cfg-2 step at batch 4."""
-    from dvf import lib as L
-    from dvf.conv import ConvFn, ReluTag
     if "geoms" not in STATE:
         test_fullsize_step_vs_oracle()
     geoms = _distinct(STATE["geoms"])
     assert len(geoms) >= 40, len(geoms)            # DispNetS: 14 + 7 + 7 + 4, PoseExpNet: 7 + 1 + 5 + 4 (some coincide)
-    L.PLAN_LOG = set()
-    failures = []
-    try:
-        for gi, (segs, cout, cfg, (n, h, w), need_in) in enumerate(geoms):
-            k, stride, pad, opad, transposed, act, alpha, beta, out_hw = cfg
-            gen = torch.Generator().manual_seed(1000 + gi)
-            cin = sum(segs)
-            xs = [torch.randn(n, c, h, w, generator=gen) for c in segs]
-            wshape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
-            wt = torch.randn(wshape, generator=gen) / (cin * k * k) ** 0.5
-            b = torch.randn(cout, generator=gen) * 0.1
-            rx = [x.clone().requires_grad_(ng) for x, ng in zip(xs, need_in)]
-            rw, rb = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
-            xin = torch.cat(rx, 1)
-            if transposed:
-                pre = F.conv_transpose2d(xin, rw, rb, stride=stride, padding=pad, output_padding=opad)
-            else:
-                pre = F.conv2d(xin, rw, rb, stride=stride, padding=pad)
-            if out_hw is not None:
-                pre = pre[:, :, :out_hw[0], :out_hw[1]]
-            ref = _ref_act(pre, act, alpha, beta)
-            gout = torch.randn(ref.shape, generator=gen)
-            if act == 1:
-                gout = gout * (pre.detach().abs() > 1e-4)       # ReLU kink: see test_gpu_conv.py
-            (ref * gout).sum().backward()
-            gx = [x.clone().to(DEV).requires_grad_(ng) for x, ng in zip(xs, need_in)]
-            gw, gb = wt.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
-            out = ConvFn.apply(gw, gb, cfg, *gx)
-            (out * gout.to(DEV)).sum().backward()
-            tag = f"{'T' if transposed else 'C'}{k}x{k}s{stride} {list(segs)}->{cout} @{h}x{w} N{n}"
-            errs = {"fwd": rel_err(out, ref), "wgrad": rel_err(gw.grad, rw.grad), "bias": rel_err(gb.grad, rb.grad)}
-            for i, (a, r) in enumerate(zip(gx, rx)):
-                if r.grad is not None:
-                    errs[f"dgrad{i}"] = rel_err(a.grad, r.grad)
-            bad = {kk: v for kk, v in errs.items() if not v < TOL}
-            if bad or tuple(out.shape) != tuple(ref.shape):
-                failures.append((tag, bad))
-            del out, gx, gw, gb, rx, rw, rb, ref, pre, gout
-            # ---- the same geometry as the step runs it (dvf/conv.py::ReluTag): inputs are outputs of ReLU layers, so the
-            # dgrad leaves multiplied by (x > 0); a ReLU layer itself receives dL/dpre (its consumers masked it) and its
-            # bias gradient is the extra column of the weight-gradient kernel (dvf_conv2d_wgrad_bias)
-            xs2 = [F.relu(x) for x in xs]
-            rx = [x.clone().requires_grad_(ng) for x, ng in zip(xs2, need_in)]
-            rw, rb = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
-            xin = torch.cat(rx, 1)
-            if transposed:
-                pre = F.conv_transpose2d(xin, rw, rb, stride=stride, padding=pad, output_padding=opad)
-            else:
-                pre = F.conv2d(xin, rw, rb, stride=stride, padding=pad)
-            if out_hw is not None:
-                pre = pre[:, :, :out_hw[0], :out_hw[1]]
-            ref = _ref_act(pre, act, alpha, beta)
-            gout = torch.randn(ref.shape, generator=gen)
-            if act == 1:
-                gout = gout * (pre.detach().abs() > 1e-4)
-            (ref * gout).sum().backward()
-            gx = [x.clone().to(DEV).requires_grad_(ng) for x, ng in zip(xs2, need_in)]
-            for x in gx:
-                x._dvf_relu_tag = ReluTag()
-            gw, gb = wt.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
-            out = ConvFn.apply(gw, gb, tuple(cfg) + ((ReluTag(),) if act == 1 else ()), *gx)
-            go = gout * (ref.detach() > 0) if act == 1 else gout        # what masking consumers deliver
-            out.backward(go.to(DEV))
-            errs = {"fused wgrad": rel_err(gw.grad, rw.grad), "fused bias": rel_err(gb.grad, rb.grad)}
-            for i, (a, r, x0) in enumerate(zip(gx, rx, xs2)):
-                if r.grad is not None:
-                    errs[f"masked dgrad{i}"] = rel_err(a.grad, r.grad * (x0 > 0))
-            bad = {kk: v for kk, v in errs.items() if not v < TOL}
-            if bad:
-                failures.append((tag, bad))
-            del out, gx, gw, gb, rx, rw, rb, ref, pre, gout, go
-    finally:
-        STATE["layer_plans"] = L.PLAN_LOG
-        L.PLAN_LOG = None
-    assert not failures, failures
+    _check_geometries(geoms, 0)
 
 
 def test_bench_plans_are_the_tested_plans():
@@ -205,3 +223,52 @@ def test_bench_plans_are_the_tested_plans():
     kernels = {p[1] for p in step}
     assert {1, 8} <= kernels, kernels                      # conv_pipe and wgrad_pipe at least
     print("%d distinct plans in the step, all parity-tested; kernels used: %s" % (len(step), sorted(kernels)))
+
+
+# ---------------------------------------------------------------------------------------------------- cfg 3 / 4 / 5
+# The other benchmark configurations (bench.CONFIGS): FeatExtractor on 3 x 8 full-resolution images
+# (reference: unsupervise.py:104-111), the 4-scale train.py body with the feature term, and 384x1280 with a five-frame
+# window (PoseExpNet_sfm.py:22-36: a 15-channel first convolution; loss_functions_sfm.py:9-46 with V = 4).  A full-size
+# ORACLE step of these is minutes of CPU time per configuration; the body arithmetic is pinned at reduced size
+# (tests/test_gpu_nets.py, golden steps).  What is shape dependent -- the convolution plans and the fused loss kernels'
+# size-dependent paths -- is pinned here: one full-size step per configuration collects every convolution geometry and
+# every plan record; each geometry not seen before is parity-checked against torch CPU at 1e-4 (plain and fused forms);
+# the step's plans must be a subset of the parity-checked plans; the step's loss must be finite.
+def _bench_module():
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("dvf_bench_for_tests", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("config", [3, 4, 5])
+def test_other_bench_configs_geometries_and_plans(config):
+    import argparse
+    from dvf import conv as C
+    from dvf import lib as L
+    bench = _bench_module()
+    cfg = bench.CONFIGS[config]
+    args = argparse.Namespace(batch=cfg["batch"], height=cfg["height"], width=cfg["width"], seed=0, force_ddp=False,
+                              no_graph=True)
+    step, fwd_bwd, opt, _ = bench.build(args, cfg, torch.device(DEV), 1, 0)
+    fwd_bwd()                                         # (first pass: packs, workspaces)
+    C.GEOM_LOG, L.PLAN_LOG = [], set()
+    try:
+        total = fwd_bwd()[0]
+        L.join_aux_streams()
+        torch.cuda.synchronize()
+    finally:
+        geoms, step_plans = _distinct(C.GEOM_LOG), L.PLAN_LOG
+        C.GEOM_LOG, L.PLAN_LOG = None, None
+    assert torch.isfinite(total).all(), float(total)
+    assert float(opt.flat_g.abs().max()) > 0 and torch.isfinite(opt.flat_g).all()
+    del step, fwd_bwd, opt
+    torch.cuda.empty_cache()
+    assert geoms and step_plans
+    _check_geometries(geoms, 10000 * config)
+    missing = sorted(step_plans - STATE["layer_plans"])
+    assert not missing, (config, missing)
+    print("cfg %d: %d geometries, %d plans, all parity-tested" % (config, len(geoms), len(step_plans)))

@@ -37,7 +37,7 @@ def test_inverse_warp_golden(name):
         assert torch.equal((out.detach().cpu() == 0).all(1), (t(g["out"]) == 0).all(1))
 
 
-@pytest.mark.parametrize("name", ["photo_c3_16x24", "photo_c3_32x104", "photo_c32_16x24"])
+@pytest.mark.parametrize("name", ["photo_c3_16x24", "photo_c3_32x104", "photo_c32_16x24", "photo_c3_32x104_rawpose"])
 def test_photometric_golden(name):
     import loss_functions as lf
     g = load_golden(name)

@@ -31,7 +31,7 @@ def test_inverse_warp(name):
         assert np.array_equal((out.detach().numpy() == 0).all(1), (g["out"] == 0).all(1))
 
 
-@pytest.mark.parametrize("name", ["photo_c3_16x24", "photo_c3_32x104", "photo_c32_16x24"])
+@pytest.mark.parametrize("name", ["photo_c3_16x24", "photo_c3_32x104", "photo_c32_16x24", "photo_c3_32x104_rawpose"])
 def test_photometric_single_scale(name):
     g = load_golden(name)
     leaves = {k: t(g[k]).requires_grad_(True) for k in ("R2", "R1", "L2", "depth", "T21", "TRL")}

@@ -70,6 +70,10 @@ def test_loader_and_batch_dict(tmp_path):
     # (t, r-euler) for pose_vec2mat (unsupervise.py / train.py) -- a 0.54 m translation along x in both, no rotation
     assert torch.equal(batch["T_R2L_se3"], torch.tensor([[0, 0, 0, -0.54, 0, 0]] * 2))
     assert torch.allclose(batch["T_R2L"], torch.tensor([[-0.54, 0, 0, 0, 0, 0]] * 2), atol=1e-7)
+    # --reference-stereo-pose: the file vector reaches pose_vec2mat unchanged, as in the reference (unsupervise.py:101)
+    ref_mode = un_dataset.to_batch(next(iter(loader)), "cpu", reference_stereo_pose=True)
+    assert torch.equal(ref_mode["T_R2L"], torch.tensor([[0, 0, 0, -0.54, 0, 0]] * 2))
+    assert torch.equal(ref_mode["T_R2L_se3"], ref_mode["T_R2L"])
 
 
 def test_se3_to_tr_euler_is_the_same_rigid_motion():
