@@ -1186,6 +1186,17 @@ int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qseg
     w.QSLOTS = CK + (w.bias_col >= 0 ? 1 : 0);
     const size_t lds = (size_t)2 * (PF + (size_t)w.QSLOTS * w.PSq) * 4;
     if (const char *e = dvf_tune("DVF_WG_DBG")) w.dbg = atoi(e);
+    w.stamps = nullptr;
+#ifdef DVF_TUNING
+    if (dvf_tune("DVF_WG_STAMPS")) {   // in-kernel cycle account of the LAST wgrad_pipe launch (tools/r3/stamps.py)
+        if (!g_stamp_buf && hipMalloc(&g_stamp_buf, STAMP_MAX_BLOCKS * 64) != hipSuccess) return DVF_ERR_LAUNCH;
+        if ((size_t)nblocks <= STAMP_MAX_BLOCKS) {
+            if (hipMemsetAsync(g_stamp_buf, 0, (size_t)nblocks * 64, st) != hipSuccess) return DVF_ERR_LAUNCH;
+            w.stamps = g_stamp_buf;
+            g_stamp_blocks = nblocks;
+        }
+    }
+#endif
     const int rc = dvf_wgrad_pipe_launch(w, MT, NTW, nblocks, lds, st, TILE);
     if (rc == DVF_OK) dvf_plan_note(DVF_K_WGRAD_PIPE, MT | (TILE << 8), NTW, w.x4, CK, o.S, w.NPIq, nblocks, (int)lds, T, w.RSq, nseg);
     if (rc == DVF_OK && bias_done) *bias_done = w.bias_col >= 0;

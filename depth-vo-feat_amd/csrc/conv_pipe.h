@@ -189,6 +189,9 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
         // with a run-time index), and ONE value it takes for divergent turns the DMA loops into waterfall loops with
         // their addresses in VGPRs (3x slower kernels).  readfirstlane pins the scalars.
         auto U = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+        // (the producers are the younger waves of their SIMDs: at equal priority each of their vector instructions waits for
+        // a gap in the MFMA wave's stream, ~300 cycles apiece on the cycle account; priority outranks age)
+        __builtin_amdgcn_s_setprio(3);
         const int nprod = U((int)(blockDim.x >> 6) - 4), pidx = wave - 4;
         const int par = U(nprod == 2 ? pidx : (pidx >> 1));   // this producer owns chunks x with x % 2 == par ...
         const int half = U(nprod == 2 ? 0 : (pidx & 1)), nhalf = U(nprod == 2 ? 1 : 2);     // ... and this share of their pieces

@@ -25,6 +25,7 @@ struct WgpArgs {
     int bias_col;        // column of the block's tile that multiplies P by a slot of ones (-1: none); QSLOTS = CK + 1 then
     int QSLOTS;          // channel slots of PSq floats per LDS stage
     int dbg;             // ablation switches (-DDVF_TUNING builds): 1 no DMA loads, 4 no MFMA, 8 no atomic epilogue
+    unsigned long long *stamps;   // -DDVF_TUNING builds: per-block cycle account (8 x u64 per block), or NULL
 };
 
 constexpr int WGP_BH = 4, WGP_BW = 32;     // pixel tile of one pipeline step: 4 rows x 32 columns of the P grid

@@ -27,6 +27,13 @@ using dvfp::OOB;
 using dvfp::tensor_rsrc;
 
 constexpr int WGP_THREADS = 512;           // 4 MFMA waves + 4 producers (one per SIMD)
+
+// one LDS-DMA piece (64 lanes x LB bytes); the lane width must be a literal of the builtin
+template <int LB>
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t r, float *dst, unsigned voff, unsigned soff) {
+    if constexpr (LB == 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)dst, 16, voff, soff, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)dst, 4, voff, soff, 0, 0);
+}
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // TILE = 32: v_mfma_f32_32x32x2_f32, 32*MT rows x 4*NTW*32 columns per block.  TILE = 16: v_mfma_f32_16x16x4_f32 (same
@@ -45,6 +52,11 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
     const int nitems = w1 - w0;
     if (nitems <= 0) return;
     if (DVF_DBG(a, 32)) return;            // (ablation: dispatch only)
+    // cycle account (tuning build): [0] prologue [1] item loop [2] of it: MFMA wave 0 at the barriers [3] of it: flushes
+    // [4] 100 MHz ticks entry -> end [5] producer 0: waiting for its DMA [6] at the barriers [7] issuing
+    unsigned long long t_entry = 0, r_entry = 0;
+    DVF_STAMP(a, t_entry);
+    DVF_STAMP_RT(a, r_entry);
     int mc = w0 / a.ntiles;                // output block: m-block = mc % mtiles, channel chunk = mc / mtiles
     int tile = w0 - mc * a.ntiles;
 
@@ -52,6 +64,10 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
         // ================================================================== producers: all LDS-DMA loads
         // the four producers (one per SIMD) take a quarter of the pieces of every item each; two LDS stages, so a
         // producer never has more than one item in flight and "my share has landed" is a plain vmcnt(0)
+        // The producers are the YOUNGER waves of their SIMDs: at equal priority every vector instruction of theirs waits for
+        // a gap in the MFMA wave's stream -- ~300 cycles per v_cndmask on the cycle account (profiles/r03_wgrad_stamps_*),
+        // which made a dozen offset selects per item cost as much as the item's 256 MFMAs.  Priority outranks age.
+        __builtin_amdgcn_s_setprio(3);
         const int pidx = wave - 4;
         const int planeP = a.GH * a.GW, planeQ = a.QH * a.QW;
         unsigned p_off[4];
@@ -80,80 +96,110 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
                 }
             }
         }
-        const __amdgpu_buffer_rsrc_t rs_p = tensor_rsrc(a.P);
+        const __amdgpu_buffer_rsrc_t rs_zero_dbg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.P), 0, 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_p = DVF_DBG(a, 512) ? rs_zero_dbg : tensor_rsrc(a.P);
         const int txy = a.tilesX * a.tilesY;
         int n = tile / txy;
         int tY = (tile - n * txy) / a.tilesX;
         int tX = tile - n * txy - tY * a.tilesX;
-        auto issue = [&](int st) {
-            float *Pst = smem + st * stage_floats;
+        // Round 3 (cycle account, tools/r3/stamps.py with STAMP_KIND=wgrad, profiles/r03_wgrad_stamps_before.txt): the
+        // producers were never waiting -- 15 DMA instructions per item took them as long as the item's 256 MFMAs took the
+        // MFMA waves (7.6 us), and the MFMA waves stood at the barriers for 20-35 % of the loop.  Not the DMA: the
+        // instruction stream around it.  Per CHANNEL the old loop re-read the segment table and the tensor pointer of the
+        // virtual concatenation from the kernel-argument buffer (dependent scalar loads, lgkmcnt(0) each) and rebuilt the
+        // descriptor; the piece loop tested its bound per piece.  Now the segment table lives in SGPRs (read once), a
+        // descriptor is built when the channel walk ENTERS a segment, the per-channel cost is two scalar adds, and the
+        // item loop is instantiated per piece count (compile-time trip counts, one contiguous stretch of code per item).
+        auto U = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+        static_assert(DVF_MAX_SEGS == 5, "segment table below");
+        const int sc0 = U(a.segC[0]), sc1 = U(a.nseg > 1 ? a.segC[1] : 0), sc2 = U(a.nseg > 2 ? a.segC[2] : 0),
+                  sc3 = U(a.nseg > 3 ? a.segC[3] : 0), sc4 = U(a.nseg > 4 ? a.segC[4] : 0);
+        const float *const q0 = a.Q[0], *const q1 = a.Q[a.nseg > 1 ? 1 : 0], *const q2 = a.Q[a.nseg > 2 ? 2 : 0],
+                    *const q3 = a.Q[a.nseg > 3 ? 3 : 0], *const q4 = a.Q[a.nseg > 4 ? 4 : 0];
+        auto segc_of = [&](int sg) __attribute__((always_inline)) { return sg == 0 ? sc0 : sg == 1 ? sc1 : sg == 2 ? sc2 : sg == 3 ? sc3 : sc4; };
+        auto segp_of = [&](int sg) __attribute__((always_inline)) { return sg == 0 ? q0 : sg == 1 ? q1 : sg == 2 ? q2 : sg == 3 ? q3 : q4; };
+        const int PSqu = U(a.PSq), NPIu = U(a.NPIq), CKu = U(a.CK), Cqu = U(a.Cq), mtu = U(a.mtiles), sfl = U(stage_floats);
+        const unsigned planeQb = (unsigned)U(planeQ << 2), planePb = (unsigned)U(planeP << 2);
+        unsigned long long w_p = 0, w_v = 0, w_q = 0;
+        auto issue = [&](int st, auto npc, auto exactc) __attribute__((always_inline)) {
+            constexpr int NP = decltype(npc)::value;
+            constexpr bool EXACT = decltype(exactc)::value;
+            float *Pst = smem + st * sfl;
             float *Qst = Pst + PF;
-            const int mb = mc % a.mtiles, cb = mc / a.mtiles;
-            const int m0 = mb * MB, c0 = cb * a.CK;
-            const int nch = min(a.CK, a.Cq - c0);
+            const int mb = mc % mtu, cb = mc / mtu;
+            const int m0 = mb * MB, c0 = cb * CKu;
+            const int nch = min(CKu, Cqu - c0);
             const int gy0 = tY * WGP_BH, gx0 = tX * WGP_BW;
             if (DVF_DBG(a, 1)) return;
+            unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            DVF_STAMP(a, s0);
             // ---- P tile: channel pairs pp = pidx, pidx+4, ...
-            {
+            if (!DVF_DBG(a, 2048)) {
                 const int mrem = a.M - m0;                         // valid channels of this m-block (> 0)
                 const int npairs = min(MB / 2, (mrem + 1) >> 1);
-                const unsigned soff0 = (unsigned)((n * a.PCtot + a.m_base + m0) * planeP + gy0 * a.GW + gx0) << 2;
+                unsigned soff = ((unsigned)((n * a.PCtot + a.m_base + m0) * planeP + gy0 * a.GW + gx0) << 2) + (unsigned)(2 * pidx) * planePb;
                 unsigned pvo[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
                     pvo[kk] = ((gy0 + p_row[kk] < a.GH) && (gx0 + p_col[kk] < a.GW)) ? p_off[kk] : OOB;
+                float *dst = Pst + pidx * WGP_PAIR;
                 for (int pp = pidx; pp < npairs; pp += 4) {
                     const bool odd_tail = (2 * pp + 1 >= mrem);    // second channel of the pair does not exist
-                    const unsigned soff = soff0 + ((unsigned)(2 * pp * planeP) << 2);
-                    float *dst = Pst + pp * WGP_PAIR;
                     if (a.x4) {
                         const unsigned vo = (odd_tail && lane >= 32) ? OOB : pvo[0];
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (lds_void_t *)dst, 16, vo, soff, 0, 0);
+                        dma_piece<16>(rs_p, dst, vo, soff);
                     } else {
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) {
                             const unsigned vo = (odd_tail && kk >= 2) ? OOB : pvo[kk];
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (lds_void_t *)(dst + (kk << 6)), 4, vo, soff, 0, 0);
+                            dma_piece<4>(rs_p, dst + (kk << 6), vo, soff);
                         }
                     }
+                    soff += 8u * planePb;
+                    dst += 4 * WGP_PAIR;
                 }
             }
+            DVF_STAMP(a, s1);
             // ---- Q patch: channels ci = pidx, pidx+4, ...
-            {
+            if (!DVF_DBG(a, 4096)) {
                 const int qy0 = gy0 * S - a.pad, qx0 = gx0 * S - a.XA;
-                unsigned qvo[WGP_MAXQ];
+                unsigned qvo[NP];
 #pragma unroll
-                for (int kk = 0; kk < WGP_MAXQ; ++kk) {
+                for (int kk = 0; kk < NP; ++kk) {
                     qvo[kk] = OOB;
-                    if (kk < a.NPIq) {
+                    if (EXACT || kk < NPIu) {
                         const int iy = qy0 + q_row[kk], ix = qx0 + q_col[kk];
                         const bool ok = (iy >= 0) && (iy < a.QH) && (ix >= 0) && (ix < a.QW);
                         qvo[kk] = ok ? ((unsigned)(iy * a.QW + ix) << 2) : OOB;
                     }
                 }
-                // virtual concatenation: channel c0 + ci of the chunk lives in segment `seg` at channel vc - seg_first
-                int seg = 0, seg_first = 0;
-                for (int ci = pidx; ci < nch; ci += 4) {
+                DVF_STAMP(a, s2);
+                // virtual concatenation: walk the segments that the chunk's channels c0 .. c0+nch-1 fall into
+                int ci = pidx, seg = 0, seg_first = 0;
+                float *dst = Qst + pidx * PSqu;
+                while (ci < nch) {
                     const int vc = c0 + ci;
-                    while (vc >= seg_first + a.segC[seg]) { seg_first += a.segC[seg]; ++seg; }
-                    const __amdgpu_buffer_rsrc_t rs_q = tensor_rsrc(a.Q[seg]);
-                    const unsigned soff = (unsigned)((n * a.segC[seg] + (vc - seg_first)) * planeQ) << 2;
-                    float *dst = Qst + ci * a.PSq;
-                    if (a.x4) {
+                    while (vc >= seg_first + segc_of(seg)) { seg_first += segc_of(seg); ++seg; }
+                    const int sgc = segc_of(seg);
+                    const int ci_end = min(nch, seg_first + sgc - c0);                 // this chunk's channels inside the segment
+                    const __amdgpu_buffer_rsrc_t rs_q = DVF_DBG(a, 1024) ? rs_zero_dbg : tensor_rsrc(segp_of(seg));
+                    unsigned soff = (unsigned)(n * sgc + (vc - seg_first)) * planeQb;
+                    for (; ci < ci_end; ci += 4) {
 #pragma unroll
-                        for (int kk = 0; kk < WGP_MAXQ; ++kk)
-                            if (kk < a.NPIq)
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_t *)(dst + (kk << 8)), 16, qvo[kk], soff, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int kk = 0; kk < WGP_MAXQ; ++kk)
-                            if (kk < a.NPIq)
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_t *)(dst + (kk << 6)), 4, qvo[kk], soff, 0, 0);
+                        for (int kk = 0; kk < NP; ++kk)
+                            if (EXACT || kk < NPIu) {
+                                if (a.x4) dma_piece<16>(rs_q, dst + (kk << 8), qvo[kk], soff);
+                                else dma_piece<4>(rs_q, dst + (kk << 6), qvo[kk], soff);
+                            }
+                        soff += 4u * planeQb;
+                        dst += 4 * PSqu;
                     }
                 }
+                DVF_STAMP(a, s3);
+                w_p += s1 - s0; w_v += s2 - s1; w_q += s3 - s2;
             }
         };
-        auto advance = [&]() {
+        auto advance = [&]() __attribute__((always_inline)) {
             ++tile;
             if (++tX == a.tilesX) {
                 tX = 0;
@@ -162,18 +208,40 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
             if (tile == a.ntiles) { tile = 0; n = 0; ++mc; }
         };
         if (DVF_DBG(a, 64)) return;        // (ablation: dispatch + prologue)
+        unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0, w_vm = 0, w_bar = 0, w_iss = 0;
         // item x lives in stage x & 1 and is issued one item ahead
-        issue(0);
-        advance();
-        for (int x = 0; x < nitems; ++x) {
-            // item x must have landed before anyone passes this barrier; item x-1 is fully consumed after it, which frees
-            // the stage item x+1 goes to
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (x + 1 < nitems) {
-                issue((x + 1) & 1);
-                advance();
+        auto item_loop = [&](auto npc, auto exactc) __attribute__((always_inline)) {
+            issue(0, npc, exactc);
+            advance();
+            for (int x = 0; x < nitems; ++x) {
+                // item x must have landed before anyone passes this barrier; item x-1 is fully consumed after it, which frees
+                // the stage item x+1 goes to
+                DVF_STAMP(a, p0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                DVF_STAMP(a, p1);
+                __builtin_amdgcn_s_barrier();
+                DVF_STAMP(a, p2);
+                if (x + 1 < nitems) {
+                    issue((x + 1) & 1, npc, exactc);
+                    advance();
+                }
+                DVF_STAMP(a, p3);
+                w_vm += p1 - p0; w_bar += p2 - p1; w_iss += p3 - p2;
             }
+        };
+        using std::integral_constant;
+        switch (NPIu) {
+            case 1: item_loop(integral_constant<int, 1>{}, std::true_type{}); break;
+            case 2: item_loop(integral_constant<int, 2>{}, std::true_type{}); break;
+            case 3: item_loop(integral_constant<int, 3>{}, std::true_type{}); break;
+            case 4: item_loop(integral_constant<int, 4>{}, std::true_type{}); break;
+            default:
+                if (NPIu <= 8) item_loop(integral_constant<int, 8>{}, std::false_type{});
+                else item_loop(integral_constant<int, WGP_MAXQ>{}, std::false_type{});
+        }
+        if (DVF_STAMPS_ON && a.stamps && pidx == 0 && lane == 0) {
+            a.stamps[8 * b + 5] = w_vm; a.stamps[8 * b + 6] = w_bar; a.stamps[8 * b + 7] = w_iss;
+            if (DVF_DBG(a, 256)) { a.stamps[8 * b + 5] = w_p; a.stamps[8 * b + 6] = w_v; a.stamps[8 * b + 7] = w_q; }   // (split of the issue time: P tile | offsets | Q patch)
         }
         return;
     }
@@ -300,15 +368,35 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
         }
     };
     if (DVF_DBG(a, 64)) return;
+    unsigned long long t_loop0 = 0, t_loop1 = 0, tb0 = 0, tb1 = 0, tf0 = 0, tf1 = 0, w_bar = 0, w_flush = 0;
+    DVF_STAMP(a, t_loop0);
     for (int x = 0; x < nitems; ++x) {
         // item x has landed (its producers waited for it) and item x-1 is fully consumed.  No vmcnt wait here: the
         // atomics of a flush stay in flight across the barrier.
+        DVF_STAMP(a, tb0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        DVF_STAMP(a, tb1);
+        w_bar += tb1 - tb0;
         if (!DVF_DBG(a, 4)) consume(x & 1);
         int mc_next = mc;
         if (++tile == a.ntiles) { tile = 0; ++mc_next; }
-        if ((x == nitems - 1 || mc_next != mc) && !DVF_DBG(a, 128)) flush(mc);
+        if ((x == nitems - 1 || mc_next != mc) && !DVF_DBG(a, 128)) {
+            DVF_STAMP(a, tf0);
+            flush(mc);
+            DVF_STAMP(a, tf1);
+            w_flush += tf1 - tf0;
+        }
         mc = mc_next;
+    }
+    DVF_STAMP(a, t_loop1);
+    if (DVF_STAMPS_ON && a.stamps && wave == 0) {
+        unsigned long long r_end = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DVF_STAMP_RT(a, r_end);
+        if (lane == 0) {
+            unsigned long long *o = a.stamps + 8 * b;
+            o[0] = t_loop0 - t_entry; o[1] = t_loop1 - t_loop0; o[2] = w_bar; o[3] = w_flush; o[4] = r_end - r_entry;
+        }
     }
 }
 

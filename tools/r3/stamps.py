@@ -3,7 +3,8 @@ producers of a block spend their cycles.  usage: stamps.py [layer filter]   (env
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("DVF_LIB", os.path.join(ROOT, "depth-vo-feat_amd/dvf/libdvf_hip_tuning.so"))
-os.environ["DVF_STAMPS"] = "1"
+KIND = os.environ.get("STAMP_KIND", "pipe")      # pipe: conv_pipe_kernel (fwd / dgrad); wgrad: wgrad_pipe_kernel
+os.environ["DVF_WG_STAMPS" if KIND == "wgrad" else "DVF_STAMPS"] = "1"
 sys.path.insert(0, os.path.join(ROOT, "depth-vo-feat_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
@@ -50,6 +51,14 @@ def account(tag):
     pb = (ctypes.c_int * 96)()
     npl = lib.dvf_conv2d_last_plans(pb, 96)
     plans = " ".join("[k%d MT%d NT%d WM%d CK%d TBU%d KS%d BN%d NST%d thr%d lds%d m%x]" % tuple(pb[i:i + 12]) for i in range(0, npl, 12) if pb[i] == 1)
+    if KIND == "wgrad":
+        plans = " ".join("[k%d MT|TILE %x NTW%d x4 %d CK%d S%d NPIq%d blocks%d lds%d T%d RSq%d nseg%d]" % tuple(pb[i:i + 12]) for i in range(0, npl, 12) if pb[i] == 8)
+        tot = med[0] + med[1]
+        clock = tot / (med[4] * 10.0)
+        us = lambda c: c / clock / 1e3
+        print(f"  {tag:6s} blocks {len(s):4d} | block {us(tot):6.1f} us @ {clock:4.2f} GHz = prologue {us(med[0]):5.1f} + loop {us(med[1]):6.1f} "
+              f"(MFMA waves at barriers {us(med[2]):5.1f}, flushing {us(med[3]):5.1f}) | producer: DMA wait {us(med[5]):5.1f}, at barriers {us(med[6]):6.1f}, issuing {us(med[7]):5.1f} {plans}")
+        return
     print(f"  {tag:6s} blocks {len(s):4d} | block {us(tot):6.1f} us @ {clock:4.2f} GHz = prologue {us(med[0]):5.1f} + loop {us(med[1]):6.1f} "
           f"(MFMA waves at barriers {us(med[2]):5.1f}) + epilogue {us(med[3]):5.1f} | producer: DMA wait {us(med[5]):5.1f}, at barriers {us(med[6]):6.1f}, issuing {us(med[7]):5.1f} {plans}")
 
@@ -67,8 +76,8 @@ for name, segs, cout, k, s, p, op, tr, act, (n, h, w) in LAYERS:
     for rep in range(2):                   # second pass: warm
         out = ConvFn.apply(wt, b, cfg, *xs)
         torch.cuda.synchronize()
-        if rep: account("fwd")
+        if rep and KIND == "pipe": account("fwd")
         g = torch.randn_like(out)
         out.backward(g)
         torch.cuda.synchronize()
-        if rep: account("dgrad")
+        if rep: account("dgrad" if KIND == "pipe" else "wgrad")
