@@ -690,10 +690,12 @@ __device__ __forceinline__ float act_grad(float g, float yv, int act, float alph
 
 // dpre = dy * act'(y) and dbias[c] += sum(dpre) in one pass.  VEC: 16-byte lanes (HW % 4 == 0), 4 independent loads in
 // flight per thread; one atomic per block.
+// part != NULL: the block's sum goes to part[c * (N * chunks) + n * chunks + chunk] instead of an atomic on dbias[c]
+// (bias_finish_kernel adds them in index order: run-to-run deterministic).
 template <bool VEC>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
                                                       float *__restrict__ dpre, float *dbias, int C, int HW, int act,
-                                                      float alpha, float beta, int chunks) {
+                                                      float alpha, float beta, int chunks, float *part = nullptr, int nper = 0) {
     __shared__ float red[4];
     const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
     const int c = plane % C;
@@ -736,8 +738,21 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ 
         s = wave_sum(s);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(&dbias[c], (red[0] + red[1]) + (red[2] + red[3]));
+        if (threadIdx.x == 0) {
+            const float t = (red[0] + red[1]) + (red[2] + red[3]);
+            if (part) part[(int64_t)c * nper + (plane / C) * chunks + chunk] = t;
+            else atomicAdd(&dbias[c], t);
+        }
     }
+}
+
+// dbias[c] += part[c][0 .. n) summed in a fixed order (64 strided lane sums, then a fixed tree); one block per channel
+__global__ __launch_bounds__(64) void bias_finish_kernel(const float *__restrict__ part, float *dbias, int n) {
+    const float *p = part + (int64_t)blockIdx.x * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += p[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) dbias[blockIdx.x] += s;
 }
 
 // ---------------------------------------------------------------------------------------- host planning
@@ -1105,8 +1120,10 @@ int dgrad_segment_unpacked(const dvf_conv_desc *d, const float *dpre, const floa
 // geometry is outside its envelope (the register-staged conv_wgrad_kernel then takes the segment).
 static int roundup(int v, int q) { return (v + q - 1) / q * q; }
 // dbias != NULL (Conv2d roles only): also dbias[m] += sum of P[m]; *bias_done says whether the launch took it.
+// ws / ws_floats: scratch for the deterministic flush (wgrad_pipe.h); *ws_need (optional) receives the floats it takes --
+// with st == nullptr and ws_need set the call only plans (size query) and launches nothing.
 int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qsegc, int nseg, hipStream_t st, float *dbias = nullptr,
-                  bool *bias_done = nullptr) {
+                  bool *bias_done = nullptr, float *ws = nullptr, int64_t ws_floats = 0, int64_t *ws_need = nullptr, bool plan_only = false) {
     if (bias_done) *bias_done = false;
     static const bool off = dvf_tune("DVF_WG_PIPE") && atoi(dvf_tune("DVF_WG_PIPE")) == 0;     // tuning knob
     if (off) return DVF_ERR_UNSUPPORTED;
@@ -1185,6 +1202,10 @@ int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qseg
     w.dbias = w.bias_col >= 0 ? dbias : nullptr;
     w.QSLOTS = CK + (w.bias_col >= 0 ? 1 : 0);
     const size_t lds = (size_t)2 * (PF + (size_t)w.QSLOTS * w.PSq) * 4;
+    const int64_t need = wgrad_pipe_slots(w, nblocks) * wgrad_pipe_slot_floats(MT, NTW, TILE);
+    if (ws_need) *ws_need = need;
+    if (plan_only) return DVF_OK;
+    w.ws = (ws && ws_floats >= need) ? ws : nullptr;
     if (const char *e = dvf_tune("DVF_WG_DBG")) w.dbg = atoi(e);
     w.stamps = nullptr;
 #ifdef DVF_TUNING
@@ -1197,8 +1218,9 @@ int wgrad_pipe_op(const WgradArgs &o, const float *const *qsegs, const int *qseg
         }
     }
 #endif
-    const int rc = dvf_wgrad_pipe_launch(w, MT, NTW, nblocks, lds, st, TILE);
-    if (rc == DVF_OK) dvf_plan_note(DVF_K_WGRAD_PIPE, MT | (TILE << 8), NTW, w.x4, CK, o.S, w.NPIq, nblocks, (int)lds, T, w.RSq, nseg);
+    int rc = dvf_wgrad_pipe_launch(w, MT, NTW, nblocks, lds, st, TILE);
+    if (rc == DVF_OK && w.ws) rc = dvf_wgrad_pipe_reduce(w, MT, NTW, nblocks, st, TILE);
+    if (rc == DVF_OK) dvf_plan_note(DVF_K_WGRAD_PIPE, MT | (TILE << 8), NTW, w.x4 | (w.ws ? 2 : 0), CK, o.S, w.NPIq, nblocks, (int)lds, T, w.RSq, nseg);
     if (rc == DVF_OK && bias_done) *bias_done = w.bias_col >= 0;
     return rc;
 }
@@ -1234,7 +1256,33 @@ int dvf_conv2d_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, 
 }
 
 static int wgrad_impl(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg, const float *dpre,
-                      float *dw, int accumulate, float *dbias, bool *bias_done, void *stream);
+                      float *dw, int accumulate, float *dbias, bool *bias_done, void *stream, float *ws = nullptr,
+                      int64_t ws_floats = 0, int64_t *ws_need = nullptr, bool plan_only = false);
+
+int64_t dvf_conv2d_wgrad_ws_floats(const dvf_conv_desc *d, const int *seg_channels, int nseg) {
+    int64_t need = 0;
+    const float *fake[DVF_MAX_SEGS];
+    for (int s = 0; s < DVF_MAX_SEGS; ++s) fake[s] = reinterpret_cast<const float *>(uintptr_t(256));   // (planning reads alignment only)
+    const int rc = wgrad_impl(d, fake, seg_channels, nseg, fake[0], const_cast<float *>(fake[0]), 1, nullptr, nullptr, nullptr, nullptr, 0,
+                              &need, true);
+    if (rc) return rc;
+    const int64_t nb = dvf_act_bwd_ws_floats(d->N, d->C_out, d->H_out * d->W_out);      // (the bias pass behind it, when one runs)
+    return need > nb ? need : nb;
+}
+
+int dvf_conv2d_wgrad_det(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                         const float *dpre, float *dw, int accumulate, float *dbias, int accumulate_dbias, float *ws,
+                         int64_t ws_floats, void *stream) {
+    if (!d) return DVF_ERR_INVALID_ARG;
+    hipStream_t st = dvf_stream(stream);
+    if (dbias && !accumulate_dbias &&
+        hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)(d->C_out > 0 ? d->C_out : 0), st) != hipSuccess)
+        return DVF_ERR_LAUNCH;
+    bool done = false;
+    const int rc = wgrad_impl(d, in_segs, seg_channels, nseg, dpre, dw, accumulate, dbias, dbias ? &done : nullptr, stream, ws, ws_floats);
+    if (rc || done || !dbias) return rc;
+    return dvf_act_bwd_det(dpre, nullptr, nullptr, dbias, d->N, d->C_out, d->H_out * d->W_out, DVF_ACT_NONE, 1.f, 0.f, 1, ws, ws_floats, stream);
+}
 
 int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
                      const float *dpre, float *dw, int accumulate, void *stream) {
@@ -1255,7 +1303,8 @@ int dvf_conv2d_wgrad_bias(const dvf_conv_desc *d, const float *const *in_segs, c
 }
 
 static int wgrad_impl(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg, const float *dpre,
-                      float *dw, int accumulate, float *dbias, bool *bias_done, void *stream) {
+                      float *dw, int accumulate, float *dbias, bool *bias_done, void *stream, float *ws, int64_t ws_floats,
+                      int64_t *ws_need, bool plan_only) {
     dvf_plan_reset();
     int rc = check_desc(d);
     if (rc) return rc;
@@ -1264,11 +1313,12 @@ static int wgrad_impl(const dvf_conv_desc *d, const float *const *in_segs, const
     if (!in_segs || !dpre || !dw) return DVF_ERR_INVALID_ARG;
     hipStream_t st = dvf_stream(stream);
     if (dvf_head_applicable(d, nseg)) {
+        if (plan_only) { if (ws_need) *ws_need = dvf_head_wgrad_ws_floats(d); return DVF_OK; }
         if (!in_segs[0]) return DVF_ERR_INVALID_ARG;
-        return dvf_head_wgrad(d, in_segs[0], dpre, dw, accumulate, st);
+        return dvf_head_wgrad(d, in_segs[0], dpre, dw, accumulate, st, ws, ws_floats);
     }
     const int KK = d->KH * d->KW;
-    if (!accumulate &&
+    if (!plan_only && !accumulate &&
         hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->C_in * d->C_out * KK, st) != hipSuccess)
         return DVF_ERR_LAUNCH;
     for (int s = 0; s < nseg; ++s)
@@ -1280,9 +1330,25 @@ static int wgrad_impl(const dvf_conv_desc *d, const float *const *in_segs, const
         a.P = dpre; a.PCtot = d->C_out; a.m_base = 0; a.M = d->C_out; a.GH = d->H_out; a.GW = d->W_out;
         a.Cq = d->C_in; a.QH = d->H_in; a.QW = d->W_in;
         a.g_mstride = (int64_t)d->C_in * KK; a.g_mbase = 0; a.g_cbase = 0;
-        const int prc = wgrad_pipe_op(a, in_segs, seg_channels, nseg, st, dbias, bias_done);
+        const int prc = wgrad_pipe_op(a, in_segs, seg_channels, nseg, st, dbias, bias_done, ws, ws_floats, ws_need, plan_only);
         if (prc != DVF_ERR_UNSUPPORTED) return prc;
     }
+    if (plan_only && d->transposed) {
+        // transposed layers: one launch per input segment; the scratch is reused, so the largest one counts
+        int64_t worst = 0;
+        for (int s = 0; s < nseg; ++s) {
+            WgradArgs a{};
+            a.KK = KK; a.KH = d->KH; a.KW = d->KW; a.N = d->N; a.S = d->stride; a.pad = d->pad; a.G = dw;
+            a.P = in_segs[s]; a.PCtot = seg_channels[s]; a.m_base = 0; a.M = seg_channels[s]; a.GH = d->H_in; a.GW = d->W_in;
+            a.Cq = d->C_out; a.QH = d->H_out; a.QW = d->W_out; a.g_mstride = (int64_t)d->C_out * KK;
+            const int qc = d->C_out;
+            int64_t need = 0;
+            if (wgrad_pipe_op(a, &dpre, &qc, 1, st, nullptr, nullptr, nullptr, 0, &need, true) == DVF_OK && need > worst) worst = need;
+        }
+        if (ws_need) *ws_need = worst;
+        return DVF_OK;
+    }
+    if (plan_only) return DVF_OK;
     int off = 0;
     for (int s = 0; s < nseg; ++s) {
         const int segc = seg_channels[s];
@@ -1299,7 +1365,7 @@ static int wgrad_impl(const dvf_conv_desc *d, const float *const *in_segs, const
             a.Q = dpre; a.QCtot = d->C_out; a.q_base = 0; a.Cq = d->C_out; a.QH = d->H_out; a.QW = d->W_out;
             a.g_mstride = (int64_t)d->C_out * KK; a.g_mbase = off; a.g_cbase = 0;
             const int qc = d->C_out;
-            const int prc = wgrad_pipe_op(a, &dpre, &qc, 1, st);
+            const int prc = wgrad_pipe_op(a, &dpre, &qc, 1, st, nullptr, nullptr, ws, ws_floats);
             if (prc == DVF_OK) { off += segc; continue; }
             if (prc != DVF_ERR_UNSUPPORTED) return prc;
         }
@@ -1385,6 +1451,40 @@ static int wgrad_impl(const dvf_conv_desc *d, const float *const *in_segs, const
     return DVF_OK;
 }
 
+static int act_bwd_chunks(int N, int C, int HW, bool has_bias) {
+    int chunks = (HW + 8191) / 8192;
+    const int64_t planes = (int64_t)N * C;
+    while (chunks > 1 && planes * chunks > 16384) chunks >>= 1;
+    // small layers: still fill the GPU -- but every block ends in ONE float atomic on dbias[c], and atomics on one address
+    // serialise (~40 ns each: 1024 blocks of a 1-channel head cost 41 us for a 10 MB pass): at most ~128 blocks per channel
+    while (planes * chunks < 1024 && HW / (chunks * 2) >= 1024 && (!has_bias || (int64_t)N * chunks * 2 <= 128)) chunks *= 2;
+    return chunks;
+}
+
+int64_t dvf_act_bwd_ws_floats(int N, int C, int HW) {
+    if (N <= 0 || C <= 0 || HW <= 0) return DVF_ERR_INVALID_ARG;
+    return (int64_t)C * N * act_bwd_chunks(N, C, HW, true);
+}
+
+int dvf_act_bwd_det(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act, float alpha,
+                    float beta, int accumulate_dbias, float *ws, int64_t ws_floats, void *stream) {
+    if (!dy || (act != DVF_ACT_NONE && !y) || N <= 0 || C <= 0 || HW <= 0) return DVF_ERR_INVALID_ARG;
+    if (!dbias || !ws || ws_floats < dvf_act_bwd_ws_floats(N, C, HW))
+        return dvf_act_bwd2(dy, y, dpre, dbias, N, C, HW, act, alpha, beta, accumulate_dbias, stream);
+    hipStream_t st = dvf_stream(stream);
+    if (!accumulate_dbias && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) return DVF_ERR_LAUNCH;
+    const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) |
+                                        reinterpret_cast<uintptr_t>(dpre)) % 16 == 0);
+    const int chunks = act_bwd_chunks(N, C, HW, true);
+    const int64_t planes = (int64_t)N * C;
+    if (vec) act_bwd_kernel<true><<<(unsigned)(planes * chunks), 256, 0, st>>>(dy, y, dpre, dbias, C, HW, act, alpha, beta, chunks, ws, N * chunks);
+    else act_bwd_kernel<false><<<(unsigned)(planes * chunks), 256, 0, st>>>(dy, y, dpre, dbias, C, HW, act, alpha, beta, chunks, ws, N * chunks);
+    DVF_LAUNCH_CHECK();
+    bias_finish_kernel<<<C, 64, 0, st>>>(ws, dbias, N * chunks);
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
 int dvf_act_bwd2(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act, float alpha,
                  float beta, int accumulate_dbias, void *stream) {
     if (!dy || (act != DVF_ACT_NONE && !y) || N <= 0 || C <= 0 || HW <= 0) return DVF_ERR_INVALID_ARG;
@@ -1393,12 +1493,8 @@ int dvf_act_bwd2(const float *dy, const float *y, float *dpre, float *dbias, int
     if (dbias && !accumulate_dbias && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) return DVF_ERR_LAUNCH;
     const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) |
                                         reinterpret_cast<uintptr_t>(dpre)) % 16 == 0);
-    int chunks = (HW + 8191) / 8192;
+    const int chunks = act_bwd_chunks(N, C, HW, dbias != nullptr);
     const int64_t planes = (int64_t)N * C;
-    while (chunks > 1 && planes * chunks > 16384) chunks >>= 1;
-    // small layers: still fill the GPU -- but every block ends in ONE float atomic on dbias[c], and atomics on one address
-    // serialise (~40 ns each: 1024 blocks of a 1-channel head cost 41 us for a 10 MB pass): at most ~128 blocks per channel
-    while (planes * chunks < 1024 && HW / (chunks * 2) >= 1024 && (!dbias || (int64_t)N * chunks * 2 <= 128)) chunks *= 2;
     if (vec) act_bwd_kernel<true><<<(unsigned)(planes * chunks), 256, 0, st>>>(dy, y, dpre, dbias, C, HW, act, alpha, beta, chunks);
     else act_bwd_kernel<false><<<(unsigned)(planes * chunks), 256, 0, st>>>(dy, y, dpre, dbias, C, HW, act, alpha, beta, chunks);
     DVF_LAUNCH_CHECK();

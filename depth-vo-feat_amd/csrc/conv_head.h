@@ -7,7 +7,10 @@ bool dvf_head_wide_applicable(const dvf_conv_desc *d, int nseg);
 int dvf_head_fwd_segs(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg, const float *w,
                       const float *bias, float *out, hipStream_t st);
 int dvf_head_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, hipStream_t st, const float *mask = nullptr);
-int dvf_head_wgrad(const dvf_conv_desc *d, const float *in, const float *dpre, float *dw, int accumulate, hipStream_t st);
+// ws (>= dvf_head_wgrad_ws_floats(d) floats): per-block partial sums + a fixed-order finish instead of float atomics
+int dvf_head_wgrad(const dvf_conv_desc *d, const float *in, const float *dpre, float *dw, int accumulate, hipStream_t st,
+                   float *ws = nullptr, int64_t ws_floats = 0);
+int64_t dvf_head_wgrad_ws_floats(const dvf_conv_desc *d);
 bool dvf_head_seg_dgrad_applicable(const dvf_conv_desc *d, int segc);
 int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int seg_off, int segc,
                        hipStream_t st, const float *mask = nullptr);     // mask: (mask > 0) ? din : 0 (ReLU backward of the segment's producer)

@@ -38,13 +38,17 @@ struct HeadSegs {                            // the input: a virtual concat of u
     int c[HEAD_MAX_SEGS];
     int n;
 };
-template <int MO>
+// HCKT input channels per staging round, FTH tile rows (8: two rows per thread; 4: one).  Full-resolution layers run
+// <8, 8>; the low-resolution heads (<= 64x208: a few dozen blocks, whose run time is the chain of their staging round
+// trips -- 16 rounds for the 128-channel head) run <32, 4>: four times fewer, four times larger rounds on twice the blocks.
+template <int MO, int HCKT, int FTH>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const float *__restrict__ w,
                                                        const float *__restrict__ bias, float *__restrict__ out, int C, int H,
                                                        int W, int tilesX, int act, float alpha, float beta, int ws_m, int ws_c,
                                                        int flip, const float *__restrict__ mask) {
-    __shared__ float tile[HCK * FP_N];
-    extern __shared__ __attribute__((aligned(16))) float wsh[];           // [MO][C][9] weights of the block (tap order already flipped if asked)
+    constexpr int ROWS = FTH / 4, FPH = FTH + 2, FPN = FPH * HP_W, FLD = (FPN + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float wsh[];           // [MO][C][9] weights of the block (tap order already flipped if asked) | tile
+    float *tile = wsh + ((MO * C * 9 + 3) & ~3);                          // [HCKT][FPN]
     // LDS layout: [m][c][9] for the 1-4 channel heads; [c][m][9] for the 16-channel variant, whose inner loop reads the 144
     // weights of a channel as 36 uniform-address ds_read_b128 (one broadcast read per four FMAs pairs instead of one per pair)
     for (int e = threadIdx.x; e < MO * C * 9; e += 256) {
@@ -54,53 +58,55 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const 
         else wsh[e] = wv;
     }
     const int n = blockIdx.y, tY = blockIdx.x / tilesX, tX = blockIdx.x - tY * tilesX;
-    const int y0 = tY * FT_H, x0 = tX * HT_W;
-    const int lx = threadIdx.x & (HT_W - 1), ly = (threadIdx.x >> 6) * 2;      // rows ly, ly+1
+    const int y0 = tY * FTH, x0 = tX * HT_W;
+    const int lx = threadIdx.x & (HT_W - 1), ly = (threadIdx.x >> 6) * ROWS;   // rows ly .. ly+ROWS-1
     const int64_t plane = (int64_t)H * W;
-    int soff[F_LD];                          // source offset inside a plane (or -1: zero / not mine)
+    int soff[FLD];                           // source offset inside a plane (or -1: zero / not mine)
 #pragma unroll
-    for (int i = 0; i < F_LD; ++i) {
+    for (int i = 0; i < FLD; ++i) {
         const int e = threadIdx.x + 256 * i, py = e / HP_W, px = e - py * HP_W;
         const int y = y0 + py - 1, x = x0 + px - 1;
-        soff[i] = (e < FP_N && y >= 0 && y < H && x >= 0 && x < W) ? y * W + x : -1;
+        soff[i] = (e < FPN && y >= 0 && y < H && x >= 0 && x < W) ? y * W + x : -1;
     }
-    float acc[2][MO];
+    float acc[ROWS][MO];
 #pragma unroll
-    for (int m = 0; m < MO; ++m) acc[0][m] = acc[1][m] = bias ? bias[m] : 0.f;
-    // the loads of chunk c0 + HCK are issued before the FMAs of chunk c0 (registers), so their latency overlaps them
-    float stg[HCK][F_LD];
+    for (int m = 0; m < MO; ++m)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) acc[r][m] = bias ? bias[m] : 0.f;
+    // the loads of chunk c0 + HCKT are issued before the FMAs of chunk c0 (registers), so their latency overlaps them
+    float stg[HCKT][FLD];
     static_assert(HEAD_MAX_SEGS == 3, "segment select below");
     auto seg_ptr = [&](int sg) { return sg == 0 ? in.p[0] : sg == 1 ? in.p[1] : in.p[2]; };
     auto seg_ch = [&](int sg) { return sg == 0 ? in.c[0] : sg == 1 ? in.c[1] : in.c[2]; };
-    auto issue = [&](int sg, int cs) {       // chunk = up to HCK channels of ONE segment, starting at its channel cs
-        const int sc = seg_ch(sg), nch = min(HCK, sc - cs);
+    auto issue = [&](int sg, int cs) {       // chunk = up to HCKT channels of ONE segment, starting at its channel cs
+        const int sc = seg_ch(sg), nch = min(HCKT, sc - cs);
         const float *src = seg_ptr(sg) + ((int64_t)n * sc + cs) * plane;
 #pragma unroll
-        for (int ch = 0; ch < HCK; ++ch)
+        for (int ch = 0; ch < HCKT; ++ch)
 #pragma unroll
-            for (int i = 0; i < F_LD; ++i) stg[ch][i] = (ch < nch && soff[i] >= 0) ? src[ch * plane + soff[i]] : 0.f;
+            for (int i = 0; i < FLD; ++i) stg[ch][i] = (ch < nch && soff[i] >= 0) ? src[ch * plane + soff[i]] : 0.f;
     };
     issue(0, 0);
     int sg = 0, cs = 0, cg = 0;              // current chunk: segment, channel inside it, channel of the concat
     while (sg < in.n) {
-        const int nch = min(HCK, seg_ch(sg) - cs);
-        int sg2 = sg, cs2 = cs + HCK;
+        const int nch = min(HCKT, seg_ch(sg) - cs);
+        int sg2 = sg, cs2 = cs + HCKT;
         if (cs2 >= seg_ch(sg)) { ++sg2; cs2 = 0; }
         __syncthreads();
 #pragma unroll
-        for (int ch = 0; ch < HCK; ++ch)
+        for (int ch = 0; ch < HCKT; ++ch)
 #pragma unroll
-            for (int i = 0; i < F_LD; ++i) {
+            for (int i = 0; i < FLD; ++i) {
                 const int e = threadIdx.x + 256 * i;
-                if (e < FP_N) tile[ch * FP_N + e] = stg[ch][i];
+                if (e < FPN) tile[ch * FPN + e] = stg[ch][i];
             }
         __syncthreads();
         if (sg2 < in.n) issue(sg2, cs2);
         for (int ch = 0; ch < nch; ++ch) {
-            const float *t = tile + ch * FP_N + ly * HP_W + lx;
-            float v[4][3];
+            const float *t = tile + ch * FPN + ly * HP_W + lx;
+            float v[ROWS + 2][3];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < ROWS + 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 3; ++b) v[a][b] = t[a * HP_W + b];
             if constexpr (MO == 16) {
@@ -115,8 +121,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const 
                     for (int k = 0; k < 9; ++k) {
                         const int f = m * 9 + k;
                         const float wk = wr[f >> 2][f & 3];
-                        acc[0][m] = fmaf(wk, v[k / 3][k % 3], acc[0][m]);
-                        acc[1][m] = fmaf(wk, v[k / 3 + 1][k % 3], acc[1][m]);
+#pragma unroll
+                        for (int r = 0; r < ROWS; ++r) acc[r][m] = fmaf(wk, v[k / 3 + r][k % 3], acc[r][m]);
                     }
             } else {
 #pragma unroll
@@ -125,8 +131,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const 
 #pragma unroll
                     for (int k = 0; k < 9; ++k) {
                         const float wk = wm[k];
-                        acc[0][m] = fmaf(wk, v[k / 3][k % 3], acc[0][m]);
-                        acc[1][m] = fmaf(wk, v[k / 3 + 1][k % 3], acc[1][m]);
+#pragma unroll
+                        for (int r = 0; r < ROWS; ++r) acc[r][m] = fmaf(wk, v[k / 3 + r][k % 3], acc[r][m]);
                     }
                 }
             }
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const 
     }
     const int x = x0 + lx;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < ROWS; ++r) {
         const int y = y0 + ly + r;
         if (y < H && x < W) {
             if (mask) {        // (segment dgrad) ReLU backward of the layer that produced this segment: its output is the mask
@@ -159,6 +165,14 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float *__restrict
                                                          float *__restrict__ din, int C, int H, int W, int tilesX,
                                                          const float *__restrict__ mask) {
     __shared__ float tile[MO * HP_H * HP_W];
+    extern __shared__ __attribute__((aligned(16))) float wsh[];           // [C][MO*9 (+pad to 4)]: the layer's weights, once per block
+    // (the per-channel loop used to fetch its 9*MO weights with scalar loads from global memory: a dependent ~0.4 us round
+    // trip per channel, 50 us for the 128-channel head at 32x104; from LDS they are broadcast reads)
+    constexpr int WPC = (MO * 9 + 3) & ~3;
+    for (int e = threadIdx.x; e < C * MO * 9; e += 256) {
+        const int c = e / (MO * 9), r = e - c * (MO * 9), m = r / 9, k = r - m * 9;
+        wsh[c * WPC + r] = w[((int64_t)m * C + c) * 9 + k];
+    }
     const int n = blockIdx.y, tY = blockIdx.x / tilesX, tX = blockIdx.x - tY * tilesX;
     const int y0 = tY * HT_H, x0 = tX * HT_W;
     const int lx = threadIdx.x & (HT_W - 1), ly = threadIdx.x >> 6;
@@ -177,24 +191,34 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float *__restrict
     const int64_t base = (int64_t)n * C * plane + (int64_t)y * W + x;
     float *dst = din + base;
     const float *mk = mask ? mask + base : nullptr;     // ReLU backward of the layer that produced the input: its output is the mask
-    for (int c = 0; c < C; ++c) {
-        float s = 0.f;
+    // four channels per trip: their mask loads are issued together and the stores leave back to back
+    for (int c0 = 0; c0 < C; c0 += 4) {
+        float sv[4], mv[4];
 #pragma unroll
-        for (int m = 0; m < MO; ++m) {
-            const float *wm = w + ((int64_t)m * C + c) * 9;
+        for (int q = 0; q < 4; ++q) {
+            const int c = min(c0 + q, C - 1);
+            mv[q] = mk ? mk[c * plane] : 1.f;
+            const float *wc = wsh + c * WPC;
+            float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) s = fmaf(wm[k], g[m][k], s);
+            for (int m = 0; m < MO; ++m)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) s = fmaf(wc[m * 9 + k], g[m][k], s);
+            sv[q] = s;
         }
-        if (mk) s = mk[c * plane] > 0.f ? s : 0.f;
-        dst[c * plane] = s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c0 + q < C) dst[(c0 + q) * plane] = (mv[q] > 0.f) ? sv[q] : 0.f;
     }
 }
 
 // dW[mo][c][ta][tb] (+)= sum_{n,y,x} dpre[n][mo][y][x] * in[n][c][y+ta-1][x+tb-1]
 // grid (channel chunks of HWK, pixel-tile groups); thread t < nch*9 owns column (c, tap) and walks the tile's pixels
+// part != NULL: the block's sums go to part[blockIdx.y][m][c][tap] (head_wgrad_finish_kernel adds the groups in order)
 template <int MO>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float *__restrict__ in, const float *__restrict__ dpre,
-                                                         float *dw, int N, int C, int H, int W, int tilesX, int tilesY) {
+                                                         float *dw, int N, int C, int H, int W, int tilesX, int tilesY,
+                                                         float *part = nullptr) {
     __shared__ float tin[HWK * HP_H * HP_W];
     __shared__ float tdp[MO * HT_H * HT_W];
     __shared__ float red[4 * HWK * 9 * MO];
@@ -240,9 +264,20 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float *__restrict
         for (int m = 0; m < MO; ++m) {
             const float s = (red[(0 * MO + m) * (HWK * 9) + lane] + red[(1 * MO + m) * (HWK * 9) + lane]) +
                             (red[(2 * MO + m) * (HWK * 9) + lane] + red[(3 * MO + m) * (HWK * 9) + lane]);
-            atomicAdd(&dw[((int64_t)m * C + c0 + col_c) * 9 + col_t], s);
+            const int64_t o = ((int64_t)m * C + c0 + col_c) * 9 + col_t;
+            if (part) part[(int64_t)blockIdx.y * MO * C * 9 + o] = s;
+            else atomicAdd(&dw[o], s);
         }
     }
+}
+
+// dw[e] += sum over groups g (in order) of part[g][e]
+__global__ __launch_bounds__(256) void head_wgrad_finish_kernel(const float *__restrict__ part, float *dw, int n, int groups) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    for (int g = 0; g < groups; ++g) s += part[(int64_t)g * n + e];
+    dw[e] += s;
 }
 
 
@@ -383,6 +418,31 @@ int dvf_dconvt_fwd(const dvf_conv_desc *d, const float *in, const float *w, cons
         default: return DVF_ERR_UNSUPPORTED;     \
     }
 
+// one forward-form launch (heads, thin full-resolution layers, narrow-segment dgrads): tile shape by resolution
+static int head_fwd_launch(int MOv, const HeadSegs &in, const float *w, const float *bias, float *out, int C, int N, int H, int W,
+                           int act, float alpha, float beta, int ws_m, int ws_c, int flip, const float *mask, hipStream_t st) {
+    const bool lowres = (int64_t)N * H * W <= (int64_t)4 * 64 * 208 && MOv <= 4 && C >= 32;
+    const int FTH = lowres ? 4 : FT_H, HCKT = lowres ? 32 : HCK;
+    const int tilesX = cdivh(W, HT_W), tilesY = cdivh(H, FTH);
+    const dim3 grid(tilesX * tilesY, N);
+    const size_t lds = ((size_t)((MOv * C * 9 + 3) & ~3) + (size_t)HCKT * (FTH + 2) * HP_W) * 4;
+#define HEAD_FWD_GO(HC, FH) head_fwd_kernel<MO, HC, FH><<<grid, 256, lds, st>>>(in, w, bias, out, C, H, W, tilesX, act, alpha, beta, ws_m, ws_c, flip, mask)
+    if (lowres) {
+        static bool big[5] = {false, false, false, false, false};
+        HEAD_DISPATCH(MOv, {
+            if (lds > 64 * 1024 && !big[MO]) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&head_fwd_kernel<MO, 32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DVF_ERR_LAUNCH;
+                big[MO] = true;
+            }
+            HEAD_FWD_GO(32, 4); });
+    } else {
+        HEAD_FWD_DISPATCH(MOv, (HEAD_FWD_GO(8, 8)));
+    }
+#undef HEAD_FWD_GO
+    DVF_LAUNCH_CHECK();
+    return DVF_OK;
+}
+
 int dvf_head_fwd(const dvf_conv_desc *d, const float *in, const float *w, const float *bias, float *out, hipStream_t st) {
     const int one = d->C_in;
     return dvf_head_fwd_segs(d, &in, &one, 1, w, bias, out, st);
@@ -398,14 +458,12 @@ bool dvf_head_wide_applicable(const dvf_conv_desc *d, int nseg) {
 
 int dvf_head_fwd_segs(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg, const float *w,
                       const float *bias, float *out, hipStream_t st) {
-    const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, FT_H);
-    const dim3 grid(tilesX * tilesY, d->N);
     HeadSegs in{};
     for (int s = 0; s < HEAD_MAX_SEGS; ++s) { in.p[s] = s < nseg ? in_segs[s] : in_segs[0]; in.c[s] = s < nseg ? seg_channels[s] : 0; }
     in.n = nseg;
-    HEAD_FWD_DISPATCH(d->C_out, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_in * 9 * 4, st>>>(
-                                    in, w, bias, out, d->C_in, d->H_in, d->W_in, tilesX, d->act, d->alpha, d->beta, d->C_in * 9, 9, 0, nullptr)));
-    DVF_LAUNCH_CHECK();
+    const int rc = head_fwd_launch(d->C_out, in, w, bias, out, d->C_in, d->N, d->H_in, d->W_in, d->act, d->alpha, d->beta,
+                                   d->C_in * 9, 9, 0, nullptr, st);
+    if (rc) return rc;
     dvf_plan_note(DVF_K_HEAD_FWD, d->C_out, nseg);
     return DVF_OK;
 }
@@ -423,15 +481,13 @@ bool dvf_head_seg_dgrad_applicable(const dvf_conv_desc *d, int segc) {
 
 int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, int seg_off, int segc,
                        hipStream_t st, const float *mask) {
-    const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, FT_H);
-    const dim3 grid(tilesX * tilesY, d->N);
     const float *wseg = w + (int64_t)seg_off * 9;
     HeadSegs in{};
     for (int s = 0; s < HEAD_MAX_SEGS; ++s) { in.p[s] = dpre; in.c[s] = s == 0 ? d->C_out : 0; }
     in.n = 1;
-    HEAD_FWD_DISPATCH(segc, (head_fwd_kernel<MO><<<grid, 256, (size_t)MO * d->C_out * 9 * 4, st>>>(
-                                in, wseg, nullptr, din, d->C_out, d->H_in, d->W_in, tilesX, DVF_ACT_NONE, 1.f, 0.f, 9, d->C_in * 9, 1, mask)));
-    DVF_LAUNCH_CHECK();
+    const int rc = head_fwd_launch(segc, in, wseg, nullptr, din, d->C_out, d->N, d->H_in, d->W_in, DVF_ACT_NONE, 1.f, 0.f, 9,
+                                   d->C_in * 9, 1, mask, st);
+    if (rc) return rc;
     dvf_plan_note(DVF_K_HEAD_SEG_DGRAD, segc);
     return DVF_OK;
 }
@@ -439,24 +495,44 @@ int dvf_head_seg_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w
 int dvf_head_dgrad(const dvf_conv_desc *d, const float *dpre, const float *w, float *din, hipStream_t st, const float *mask) {
     const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, HT_H);
     const dim3 grid(tilesX * tilesY, d->N);
-    HEAD_DISPATCH(d->C_out, (head_dgrad_kernel<MO><<<grid, 256, 0, st>>>(dpre, w, din, d->C_in, d->H_in, d->W_in, tilesX, mask)));
+    HEAD_DISPATCH(d->C_out, (head_dgrad_kernel<MO><<<grid, 256, (size_t)d->C_in * ((MO * 9 + 3) & ~3) * 4, st>>>(
+                                dpre, w, din, d->C_in, d->H_in, d->W_in, tilesX, mask)));
     DVF_LAUNCH_CHECK();
     dvf_plan_note(DVF_K_HEAD_DGRAD, d->C_out);
     return DVF_OK;
 }
 
-int dvf_head_wgrad(const dvf_conv_desc *d, const float *in, const float *dpre, float *dw, int accumulate, hipStream_t st) {
-    if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->C_out * d->C_in * 9, st) != hipSuccess)
-        return DVF_ERR_LAUNCH;
-    const int tilesX = cdivh(d->W_in, HT_W), tilesY = cdivh(d->H_in, HT_H);
-    const int chunks = cdivh(d->C_in, HWK), ntiles = d->N * tilesX * tilesY;
-    int groups = 2048 / chunks;
+static void head_wgrad_grid(const dvf_conv_desc *d, int &tilesX, int &tilesY, int &chunks, int &groups) {
+    tilesX = cdivh(d->W_in, HT_W); tilesY = cdivh(d->H_in, HT_H);
+    chunks = cdivh(d->C_in, HWK);
+    const int ntiles = d->N * tilesX * tilesY;
+    groups = 2048 / chunks;
     if (groups < 1) groups = 1;
     if (groups > ntiles) groups = ntiles;
+}
+
+int64_t dvf_head_wgrad_ws_floats(const dvf_conv_desc *d) {
+    int tilesX, tilesY, chunks, groups;
+    head_wgrad_grid(d, tilesX, tilesY, chunks, groups);
+    return (int64_t)groups * d->C_out * d->C_in * 9;
+}
+
+int dvf_head_wgrad(const dvf_conv_desc *d, const float *in, const float *dpre, float *dw, int accumulate, hipStream_t st,
+                   float *ws, int64_t ws_floats) {
+    if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->C_out * d->C_in * 9, st) != hipSuccess)
+        return DVF_ERR_LAUNCH;
+    int tilesX, tilesY, chunks, groups;
+    head_wgrad_grid(d, tilesX, tilesY, chunks, groups);
     const dim3 grid(chunks, groups);
+    float *part = (ws && ws_floats >= dvf_head_wgrad_ws_floats(d)) ? ws : nullptr;
     HEAD_DISPATCH(d->C_out, (head_wgrad_kernel<MO><<<grid, 256, 0, st>>>(in, dpre, dw, d->N, d->C_in, d->H_in, d->W_in, tilesX,
-                                                                        tilesY)));
+                                                                        tilesY, part)));
     DVF_LAUNCH_CHECK();
-    dvf_plan_note(DVF_K_HEAD_WGRAD, d->C_out);
+    if (part) {
+        const int n = d->C_out * d->C_in * 9;
+        head_wgrad_finish_kernel<<<(n + 255) / 256, 256, 0, st>>>(part, dw, n, groups);
+        DVF_LAUNCH_CHECK();
+    }
+    dvf_plan_note(DVF_K_HEAD_WGRAD, d->C_out, part ? 1 : 0);
     return DVF_OK;
 }

@@ -255,15 +255,11 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
         OHc = c.OHc > OHc ? c.OHc : OHc; OWc = c.OWc > OWc ? c.OWc : OWc;
     }
     const PipeOverride ov = pipe_override();
-    // Layers with at most 32 output channels have little MFMA work per staged input byte: their patch DMA (4-byte
-    // lanes) saturates the texture-address path before the matrix pipe, and the register-staged conv_gather_kernel is
-    // faster (tools/conv_bench.py, round 1).  They stay on that kernel until the patch is staged in 16-byte lanes.
-    // (tried in round 1: staging the patch in 16-byte lanes -- 4x SLOWER than 4-byte lanes for these short row-strided
-    // runs, loads-only 82 us vs 30 us on the 3x3 128->128 @32x104 layer -- so that is not the way to bring them over)
-    // (measured per layer with tools/conv_bench.py: at 17..32 channels the pipelined kernel still wins for the 5x5 / 7x7
-    // kernels and for the output-parity classes of stride-2 layers, where a chunk carries many taps per staged byte)
+    // Layers with at most 16 output channels stay on the register-staged conv_gather_kernel (half of a 32-row MFMA tile would
+    // be padding); 17..32 channels run here since round 3 (with the rewritten producers the pipelined kernel wins for the 3x3
+    // layers too: 3x3 65->32 @128x416 forward 0.143 -> 0.121 ms in the step).
     static const int smallm = dvf_tune("DVF_PIPE_SMALLM") ? atoi(dvf_tune("DVF_PIPE_SMALLM")) : 0;      // tuning knob
-    const bool small_ok = (a.M > 16 && (ncls > 1 || Tmax >= 25)) || ((smallm & 1) && a.M <= 16 && ncls > 1) ||
+    const bool small_ok = a.M > 16 || ((smallm & 1) && a.M <= 16 && ncls > 1) ||
                           ((smallm & 2) && a.M <= 16) || ((smallm & 4) && a.M > 16);
     if (a.M <= 32 && !ov.on && !small_ok) return DVF_ERR_UNSUPPORTED;
     if (ov.on && ov.KS < 0) return DVF_ERR_UNSUPPORTED;      // (tuning: force the gather kernel)
@@ -384,6 +380,15 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
         if ((int64_t)a.N * a.segC[s2] * a.IH * a.IW * 4 >= ((int64_t)1 << 31) - 16) return DVF_ERR_UNSUPPORTED;
     pl.MT = MT; pl.NT = NT; pl.WM = WM; pl.CKH = CK / 2; pl.TBU = TBU; pl.lds = dd.lds;
     pl.grid = dim3(a.tilesX * a.tilesY, mblocks, a.NG * KS * ncls);
+    // blocked accumulation (conv_pipe.h, BLK): reductions of 512 and more terms per block (channels x taps of its K range),
+    // on grids that give a block a CU to itself anyway (the variant needs the registers of two waves per SIMD)
+    {
+        const int64_t kseq = (int64_t)cdiv(a.NCH, KS) * CK * TAmax * TBmax;
+        static const int blk_knob = dvf_tune("DVF_PIPE_BLK") ? atoi(dvf_tune("DVF_PIPE_BLK")) : -1;     // tuning: 0 off, 1 wherever built
+        const bool built = MT == 2 && NT == 1 && WM == 1 && CK >= 8 && TBU >= 2 && TBU <= 4;
+        const bool whole_cu = (int64_t)pl.grid.x * pl.grid.y * pl.grid.z <= 256 || pl.lds > 76 * 1024;
+        a.blk = (built && whole_cu && (blk_knob == 1 || (blk_knob != 0 && kseq >= 512))) ? 1 : 0;
+    }
     // a block that has a CU to itself (by LDS size or by grid size) gets four producer waves, one per SIMD
     {
         const int64_t nblocks_total = (int64_t)pl.grid.x * pl.grid.y * pl.grid.z;
@@ -449,7 +454,7 @@ int pipe_run(PipeOp &op, const float *packed, float *ws, int64_t ws_floats, hipS
     if (a.x4)
         for (int s2 = 0; s2 < a.nseg; ++s2)
             if (reinterpret_cast<uintptr_t>(a.in[s2]) & 15) return DVF_ERR_UNSUPPORTED;    // (a view at an odd element offset)
-    dvf_plan_note(DVF_K_PIPE, pl.MT, pl.NT, pl.WM, 2 * pl.CKH, pl.TBU, a.KS, a.BN, a.NST, pl.threads, (int)pl.lds, mode | (a.ncls << 4) | (a.x4 << 8));
+    dvf_plan_note(DVF_K_PIPE, pl.MT, pl.NT, pl.WM, 2 * pl.CKH, pl.TBU, a.KS, a.BN, a.NST, pl.threads, (int)pl.lds, mode | (a.ncls << 4) | (a.x4 << 8) | (a.blk << 9));
     if (dvf_tune("DVF_PIPE_DEBUG"))
         fprintf(stderr, "[pipe] M %d chunks %d N %d out %dx%d cls %d | MT %d NT %d WM %d CK %d TBU %d KS %d BN %d tile %dx%d "
                 "(sub %dx%d) grid %ux%ux%u lds %zu x%d mode %d\n", a.M, a.NCH, a.N, a.OH, a.OW, a.ncls, pl.MT, pl.NT, pl.WM,

@@ -24,6 +24,11 @@ struct WgpArgs {
     float *dbias;        // bias gradient of a Conv2d layer (P = dL/dpre): dbias[m] += sum over pixels of P[m], or NULL
     int bias_col;        // column of the block's tile that multiplies P by a slot of ones (-1: none); QSLOTS = CK + 1 then
     int QSLOTS;          // channel slots of PSq floats per LDS stage
+    // Deterministic flush (ws != NULL): a block stores the accumulator set it holds when its item range leaves output
+    // block mc as one plain, coalesced slab, ws[(block + mc) * slot .. ) -- (block + mc) is unique per (block, mc) pair
+    // because the ranges are contiguous and ordered -- and wgrad_reduce_kernel adds the slabs of every output block in
+    // block order into G / dbias.  ws == NULL: float atomics straight into G (order of arrival).
+    float *ws;
     int dbg;             // ablation switches (-DDVF_TUNING builds): 1 no DMA loads, 4 no MFMA, 8 no atomic epilogue
     unsigned long long *stamps;   // -DDVF_TUNING builds: per-block cycle account (8 x u64 per block), or NULL
 };
@@ -36,3 +41,7 @@ constexpr size_t WGP_LDS_CAP = 160 * 1024;
 // (MT, NTW) in {1,2}^2; S in {1,2}.  Returns DVF_OK / DVF_ERR_*.
 // tile = 32: 32*MT rows x 128*NTW columns per block (NTW 1..2); tile = 16: 16*MT rows x 64*NTW columns (NTW 1..4)
 int dvf_wgrad_pipe_launch(const WgpArgs &a, int MT, int NTW, int nblocks, size_t lds_bytes, hipStream_t st, int tile = 32);
+int dvf_wgrad_pipe_reduce(const WgpArgs &a, int MT, int NTW, int nblocks, hipStream_t st, int tile);
+// floats of one flush slab of the (MT, NTW, tile) variant, and the number of slabs a launch of `nblocks` blocks may write
+inline int64_t wgrad_pipe_slot_floats(int MT, int NTW, int tile) { return (int64_t)tile * MT * 4 * NTW * tile; }
+inline int64_t wgrad_pipe_slots(const WgpArgs &a, int nblocks) { return (int64_t)nblocks + (int64_t)a.mtiles * a.cchunks; }

@@ -331,6 +331,20 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
     };
     // add the accumulators to output block `mcv` (row = P channel, column = (c, tap)) and clear them
     auto flush = [&](int mcv) {
+        if (a.ws) {
+            // plain stores, 1 KiB per wave-instruction: slab[((m * NTW + u) * NACC + r) * 256 + wave * 64 + lane]
+            float *slab = a.ws + (int64_t)(b + mcv) * (MB * 4 * NTW * TILE) + wave * 64 + lane;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int u = 0; u < NTW; ++u)
+#pragma unroll
+                    for (int r = 0; r < NACC; ++r) {
+                        slab[((m * NTW + u) * NACC + r) * 256] = DVF_DBG(a, 8) ? 0.f : acc[m][u][r];
+                        acc[m][u][r] = 0.f;
+                    }
+            return;
+        }
         const int mb = mcv % a.mtiles, cb = mcv / a.mtiles;
         const int m0 = mb * MB, c0 = cb * a.CK;
         const int nch = min(a.CK, a.Cq - c0);
@@ -420,7 +434,60 @@ int launch_s(const WgpArgs &a, int nblocks, size_t lds, hipStream_t st) {
     return DVF_ERR_UNSUPPORTED;
 }
 
+// Second half of the deterministic flush: G (+)= the slabs of every output block, summed in block order.  One thread per
+// slab element e = ((m * NTW + u) * NACC + r) * 256 + wave * 64 + lane of one output block mc; the blocks whose item
+// ranges [W*b/nb, W*(b+1)/nb) intersect mc's items [mc*ntiles, (mc+1)*ntiles) are consecutive.  The final add into G is
+// one float atomic per element and launch (G may be shared with another launch on another stream; two contributions
+// commute exactly).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgpArgs a, int MT, int NTW, int TILE, int nb) {
+    const int NACC = TILE == 32 ? 16 : 4, MB = TILE * MT, slot = MB * 4 * NTW * TILE;
+    const int mc = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    // blocks that hold items of mc (the same for the whole block: one thread does the 64-bit divisions):
+    // first b with w1(b) > mc*ntiles ... last b with w0(b) < (mc+1)*ntiles
+    __shared__ int brange[2];
+    if (threadIdx.x == 0) {
+        const int64_t lo = (int64_t)mc * a.ntiles, hi = lo + a.ntiles, Wt = a.W;
+        int b0 = (int)((lo * nb) / Wt);
+        while (b0 > 0 && (Wt * b0) / nb > lo) --b0;
+        while ((Wt * (b0 + 1)) / nb <= lo) ++b0;
+        int b1 = (int)((hi * nb) / Wt);
+        if (b1 > nb) b1 = nb;
+        while (b1 < nb && (Wt * b1) / nb < hi) ++b1;
+        while (b1 > b0 + 1 && (Wt * (b1 - 1)) / nb >= hi) --b1;
+        brange[0] = b0;
+        brange[1] = b1;                      // exclusive
+    }
+    __syncthreads();
+    if (e >= slot) return;
+    const int lane = e & 63, wave = (e >> 6) & 3, q = e >> 8;
+    const int r = q % NACC, mu = q / NACC, u = mu % NTW, m = mu / NTW;
+    const int nl = lane & (TILE - 1), kh = lane / TILE;
+    const int row = (TILE == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) : m * 16 + r) + 4 * kh;
+    const int j = (wave * NTW + u) * TILE + nl;
+    const int mb = mc % a.mtiles, cb = mc / a.mtiles;
+    const int m0 = mb * MB, c0 = cb * a.CK, nch = min(a.CK, a.Cq - c0);
+    if (m0 + row >= a.M) return;
+    const int T = a.KH * a.KW;
+    const int cj = j / T, tj = j - cj * T;
+    const bool is_bias = (j == a.bias_col);
+    if (!is_bias && !(cj < a.CK && cj < nch)) return;
+    if (is_bias && (cb != 0 || !a.dbias)) return;
+    const int b0 = brange[0], b1 = brange[1];
+    const float *src = a.ws + (int64_t)(b0 + mc) * slot + e;
+    float s = 0.f;
+    for (int b = b0; b < b1; ++b, src += slot) s += *src;
+    if (is_bias) atomicAdd(a.dbias + m0 + row, s);
+    else atomicAdd(a.G + (int64_t)(a.g_mbase + m0 + row) * a.g_mstride + (int64_t)(a.g_cbase + c0 + cj) * a.KK + tj, s);
+}
+
 }  // namespace
+
+int dvf_wgrad_pipe_reduce(const WgpArgs &a, int MT, int NTW, int nblocks, hipStream_t st, int tile) {
+    const int slot = tile * MT * 4 * NTW * tile;
+    wgrad_reduce_kernel<<<dim3((slot + 255) / 256, a.mtiles * a.cchunks), 256, 0, st>>>(a, MT, NTW, tile, nblocks);
+    return hipGetLastError() == hipSuccess ? DVF_OK : DVF_ERR_LAUNCH;
+}
 
 int dvf_wgrad_pipe_launch(const WgpArgs &a, int MT, int NTW, int nblocks, size_t lds, hipStream_t st, int tile) {
     if (nblocks < 1 || lds > WGP_LDS_CAP || a.NPIq > WGP_MAXQ) return DVF_ERR_UNSUPPORTED;

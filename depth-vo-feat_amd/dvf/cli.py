@@ -24,6 +24,9 @@ def add_common_flags(parser):
     g.add_argument("--width", type=int, default=832)
     g.add_argument("--steps-per-epoch", type=int, default=50, help="synthetic iterations per epoch")
     g.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    g.add_argument("--deterministic", action="store_true",
+                   help="weight / bias gradients summed in a fixed order (no float atomics): runs from identical state are "
+                        "bit-identical, as on the reference's CPU path; costs ~5 %% of a step")
     g.add_argument("--reference-stereo-pose", action="store_true",
                    help="feed the dataset's T_R2L file vector (0,0,0,Tx,0,0) unchanged into pose_vec2mat / the stereo-pose "
                         "MSE target, exactly as the reference does (unsupervise.py:101, train.py:201); default: convert it "
@@ -82,6 +85,9 @@ def validate(pose_net, val_loader, device):
 def run_training(args, nets, loss_fn, lr, betas, weight_decay, term_names, ckpt_names, n_views=2, val_fn=None):
     """Epoch loop.  ``loss_fn(batch) -> (loss, terms)``; ``nets``: list of modules in optimizer-group order."""
     rank, world, device = args._rank, args._world, args._device
+    if getattr(args, "deterministic", False):
+        from . import conv as _conv
+        _conv.set_deterministic(True)
     params = [p for net in nets for p in net.parameters()]
     opt = FlatAdam(params, lr=lr, betas=betas, weight_decay=weight_decay, world_size=world, overlap=True)
     batch = synthetic_batch(args.batch_size, args.height, args.width, seed=1234 + args.seed, rank=rank, n_views=n_views,

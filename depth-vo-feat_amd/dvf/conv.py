@@ -155,6 +155,38 @@ def _packed_weights(weight, holder, desc, segc, kind):
     return buf, (_workspace(ent[2], weight.device) if ent[2] else None)
 
 
+DETERMINISTIC = False   # True: weight / bias gradients are summed in a fixed order (scratch + ordered finish) instead of with
+                        # float atomics in order of arrival: bit-identical gradient arenas from identical state, as on the
+                        # reference's CPU path, for ~5 % of a cfg-2 step (set_deterministic(); entry scripts: --deterministic)
+
+
+def set_deterministic(on=True):
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+
+
+def _bias_sums(lib, dy, y, dpre, dbias, N, C, HW, act, alpha, beta, accumulate):
+    """dvf_act_bwd2 (dpre = dy * act'(y), dbias (+)= channel sums), through the deterministic entry when asked."""
+    if DETERMINISTIC and dbias is not None:
+        ws = _workspace(int(lib.dvf_act_bwd_ws_floats(N, C, HW)), dy.device)
+        L.check(lib.dvf_act_bwd_det(L.dev(dy, "grad_out"), L.dev(y), L.dev(dpre), L.dev(dbias), N, C, HW, act, alpha, beta,
+                                    1 if accumulate else 0, L.dev(ws), ws.numel(), L.stream()), "dvf_act_bwd_det")
+    else:
+        L.check(lib.dvf_act_bwd2(L.dev(dy, "grad_out"), L.dev(y), L.dev(dpre), L.dev(dbias), N, C, HW, act, alpha, beta,
+                                 1 if accumulate else 0, L.stream()), "dvf_act_bwd2")
+
+
+def _wgrad_ws_floats(holder, desc, segc):
+    """Scratch floats of the deterministic weight-gradient flush for this layer geometry (cached on the parameter)."""
+    cache = holder.__dict__.setdefault("_dvf_wgws", {})
+    key = (desc.N, desc.H_in, desc.W_in, desc.H_out, desc.W_out, desc.stride, desc.pad, desc.transposed, tuple(segc))
+    n = cache.get(key)
+    if n is None:
+        n = int(L.lib().dvf_conv2d_wgrad_ws_floats(ctypes.byref(desc), L.int_array(segc), len(segc)))
+        cache[key] = n = max(n, 0)
+    return n
+
+
 GEOM_LOG = None   # set to a list(): ConvFn.forward appends the geometry of every call (tests: bench-shape parity)
 FUSE_RELU_BWD = True   # False: every layer runs its own activation backward pass (dvf_act_bwd2), as in round 1
 
@@ -241,13 +273,11 @@ class ConvFn(torch.autograd.Function):
         elif desc.act != L.ACT_NONE:
             dpre = torch.empty_like(gout)
             with L.timed("act_bwd", 0.0, 12.0 * gout.numel()):
-                L.check(lib.dvf_act_bwd2(L.dev(gout, "grad_out"), L.dev(out), L.dev(dpre), L.dev(dbias), N, cout, oh * ow,
-                                         desc.act, desc.alpha, desc.beta, 1 if acc_b else 0, L.stream()), "dvf_act_bwd2")
+                _bias_sums(lib, gout, out, dpre, dbias, N, cout, oh * ow, desc.act, desc.alpha, desc.beta, acc_b)
         else:
             dpre = gout
             if need_b:
-                L.check(lib.dvf_act_bwd2(L.dev(gout), None, None, L.dev(dbias), N, cout, oh * ow, L.ACT_NONE, 1.0, 0.0,
-                                         1 if acc_b else 0, L.stream()), "dvf_act_bwd2")
+                _bias_sums(lib, gout, None, None, dbias, N, cout, oh * ow, L.ACT_NONE, 1.0, 0.0, acc_b)
         gins = [torch.empty_like(x) if need else None for x, need in zip(inputs, need_in)]
         if any(need_in):
             frac = sum(c for c, need in zip(segc, need_in) if need) / float(sum(segc))
@@ -277,8 +307,7 @@ class ConvFn(torch.autograd.Function):
             L.note_plans("dgrad")
         dw = None
         if fused_out and need_b and not need_w:     # (frozen weights, trainable bias: one reduction pass over dpre)
-            L.check(lib.dvf_act_bwd2(L.dev(dpre), None, None, L.dev(dbias), N, cout, oh * ow, L.ACT_NONE, 1.0, 0.0,
-                                     1 if acc_b else 0, L.stream()), "dvf_act_bwd2")
+            _bias_sums(lib, dpre, None, None, dbias, N, cout, oh * ow, L.ACT_NONE, 1.0, 0.0, acc_b)
         if need_w:
             arena = ctx.wparam is not None
             dw = ctx.wparam._dvf_grad if arena else torch.empty_like(weight)
@@ -286,14 +315,14 @@ class ConvFn(torch.autograd.Function):
             side = ctx.wparam._dvf_owner.fork_wgrad(dpre, *inputs) if arena else None
             with (torch.cuda.stream(side) if side is not None else _NullCtx()):
                 with L.timed("conv_wgrad", 2 * ctx.macs, tag=ctx.tag):
-                    if fused_out and need_b:
-                        L.check(lib.dvf_conv2d_wgrad_bias(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
-                                                          L.dev(dpre), L.dev(dw), 1 if arena else 0, L.dev(dbias),
-                                                          1 if acc_b else 0, L.stream()), "dvf_conv2d_wgrad_bias")
-                    else:
-                        L.check(lib.dvf_conv2d_wgrad(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
-                                                     L.dev(dpre), L.dev(dw), 1 if arena else 0, L.stream()),
-                                "dvf_conv2d_wgrad")
+                    # (DETERMINISTIC: partial tiles through a per-stream scratch, summed in fixed order; else float atomics)
+                    wsf = _wgrad_ws_floats(ctx.wparam if arena else weight, desc, segc) if DETERMINISTIC else 0
+                    wws = _workspace(wsf, dpre.device) if wsf > 0 else None
+                    L.check(lib.dvf_conv2d_wgrad_det(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
+                                                     L.dev(dpre), L.dev(dw), 1 if arena else 0,
+                                                     L.dev(dbias) if (fused_out and need_b) else None, 1 if acc_b else 0,
+                                                     L.dev(wws), wws.numel() if wws is not None else 0, L.stream()),
+                            "dvf_conv2d_wgrad_det")
                     L.note_plans("wgrad")
             if arena:
                 ctx.wparam._dvf_owner.grad_ready(ctx.wparam)

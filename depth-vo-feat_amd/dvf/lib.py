@@ -68,6 +68,8 @@ SIGNATURES = {
     "dvf_conv2d_dgrad_ws": (c_i, [c_desc, c_fp, c_fp, c_pp, c_ip, c_i, c_fp, c_i64, c_fp]),
     "dvf_conv2d_wgrad": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_i, c_fp]),
     "dvf_conv2d_wgrad_bias": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_i, c_fp, c_i, c_fp]),
+    "dvf_conv2d_wgrad_ws_floats": (c_i64, [c_desc, c_ip, c_i]),
+    "dvf_conv2d_wgrad_det": (c_i, [c_desc, c_pp, c_ip, c_i, c_fp, c_fp, c_i, c_fp, c_i, c_fp, c_i64, c_fp]),
     "dvf_conv2d_packed_floats": (c_i64, [c_desc, c_ip, c_i, c_i]),
     "dvf_conv2d_pack": (c_i, [c_desc, c_ip, c_i, c_i, c_fp, c_fp, c_fp]),
     "dvf_conv2d_ws_floats": (c_i64, [c_desc, c_ip, c_i, c_i]),
@@ -78,6 +80,8 @@ SIGNATURES = {
     "dvf_conv2d_dgrad_masked": (c_i, [c_desc, c_fp, c_fp, c_fp, c_pp, c_ip, c_i, c_fp, c_i64, c_pp, c_pp, c_fp]),
     "dvf_act_bwd": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_fp]),
     "dvf_act_bwd2": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_i, c_fp]),
+    "dvf_act_bwd_ws_floats": (c_i64, [c_i, c_i, c_i]),
+    "dvf_act_bwd_det": (c_i, [c_fp] * 4 + [c_i] * 4 + [c_f, c_f, c_i, c_fp, c_i64, c_fp]),
     "dvf_resize_bilinear_fwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp]),
     "dvf_upsample2x_bwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_fp]),
     "dvf_recip_fwd": (c_i, [c_fp, c_fp, c_f, c_i64, c_fp]),

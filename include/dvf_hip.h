@@ -190,6 +190,14 @@ int dvf_conv2d_wgrad(const dvf_conv_desc *d, const float *const *in_segs, const 
  * dpre tile by one more column -- of ones -- so no extra pass reads dpre; otherwise one reduction pass runs after it. */
 int dvf_conv2d_wgrad_bias(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
                           const float *dpre, float *dw, int accumulate, float *dbias, int accumulate_dbias, void *stream);
+/* Run-to-run DETERMINISTIC weight (+ bias, dbias may be NULL) gradient -- the reference's CPU path is (torch CPU
+ * ConvolutionBackward, train.py:213).  The pipelined kernel splits the pixel reduction over all CUs; with a scratch buffer of
+ * dvf_conv2d_wgrad_ws_floats(...) floats every block stores its partial tiles and one pass adds them in block order, instead
+ * of float atomics in order of arrival (ws == NULL or too small: the atomic form of dvf_conv2d_wgrad / _wgrad_bias). */
+int64_t dvf_conv2d_wgrad_ws_floats(const dvf_conv_desc *d, const int *seg_channels, int nseg);
+int dvf_conv2d_wgrad_det(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg,
+                         const float *dpre, float *dw, int accumulate, float *dbias, int accumulate_dbias, float *ws,
+                         int64_t ws_floats, void *stream);
 
 /* Packed-weight fast path: LDS-DMA pipelined kernels that read the weights from a pre-packed copy (the exact LDS
  * image of every reduction chunk), same results as dvf_conv2d_fwd / dvf_conv2d_dgrad.  op_kind 0 = forward,
@@ -247,6 +255,11 @@ int dvf_act_bwd(const float *dy, const float *y, float *dpre, float *dbias, int 
  * lives in a zeroed gradient arena needs neither a memset nor a separate add). */
 int dvf_act_bwd2(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act, float alpha,
                  float beta, int accumulate_dbias, void *stream);
+/* dvf_act_bwd2 with a run-to-run deterministic bias gradient: per-block partial sums go through ws
+ * (>= dvf_act_bwd_ws_floats(N, C, HW) floats) and are added in index order instead of float atomics on dbias[c]. */
+int64_t dvf_act_bwd_ws_floats(int N, int C, int HW);
+int dvf_act_bwd_det(const float *dy, const float *y, float *dpre, float *dbias, int N, int C, int HW, int act, float alpha,
+                    float beta, int accumulate_dbias, float *ws, int64_t ws_floats, void *stream);
 
 /* ---------------------------------------------------------------- memory-bound helpers
  * planes = N*C throughout. */

@@ -64,9 +64,13 @@ def test_packed_weight_planner_is_host_only_and_consistent():
     assert lib.dvf_conv2d_packed_floats(ctypes.byref(d), segs, 1, 1) >= 128 * 128 * 9
     assert lib.dvf_conv2d_ws_floats(ctypes.byref(d), segs, 1, 0) >= 0
     assert lib.dvf_conv2d_packed_floats(ctypes.byref(d), segs, 1, 7) == -1          # bad op_kind
-    # at most 32 output channels: stays on the unpacked kernels
-    small = _desc(4, 65, 128, 416, 32)
-    assert lib.dvf_conv2d_packed_floats(ctypes.byref(small), L.int_array([32, 32, 1]), 3, 0) == L.ERR_UNSUPPORTED
+    # at most 16 output channels: stays on the unpacked kernels (17..32 run the pipelined kernel since round 3)
+    small = _desc(4, 17, 256, 832, 16)
+    assert lib.dvf_conv2d_packed_floats(ctypes.byref(small), L.int_array([16, 1]), 2, 0) == L.ERR_UNSUPPORTED
+    mid = _desc(4, 65, 128, 416, 32)
+    assert lib.dvf_conv2d_packed_floats(ctypes.byref(mid), L.int_array([32, 32, 1]), 3, 0) >= 32 * 65 * 9
+    # deterministic weight gradient: scratch size is a host-side plan too
+    assert lib.dvf_conv2d_wgrad_ws_floats(ctypes.byref(d), segs, 1) > 0
     # virtual concat with a 1-channel segment: the wide segments are packed for dgrad, the narrow one is not
     cat = _desc(4, 257, 32, 104, 128)
     segs3 = L.int_array([128, 128, 1])

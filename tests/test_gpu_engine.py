@@ -160,3 +160,37 @@ def test_eager_convolutions_between_graph_replays_see_fresh_weights():
         assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-6), (i, a, b)
     # and the weights did move between validations (otherwise the test shows nothing)
     assert float((results["eager"][0] - results["eager"][2]).abs().max()) > 1e-4 * float(results["eager"][0].abs().max())
+
+
+def test_deterministic_mode_gradient_arena_is_bit_identical():
+    """dvf.conv.set_deterministic(True): three runs of the cfg-2 step from identical state leave bit-identical gradient arenas
+    (the reference's CPU path is run-to-run deterministic; the default build sums weight gradients with float atomics).  Run on
+    the three-stream schedule the benchmark uses, at a size where the Stream-K split spreads every layer over many blocks."""
+    import DispNetS
+    import PoseExpNet
+    from dvf import conv as C
+    from dvf import lib as L
+    from dvf.engine import FlatAdam
+    from dvf.steps import unsupervise_losses
+    from dvf.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    disp, pose = DispNetS.DispNetS(), PoseExpNet.PoseExpNet(output_exp=True)
+    disp.init_weights(); pose.init_weights()
+    disp.to(DEV).train(); pose.to(DEV).train()
+    opt = FlatAdam(list(pose.parameters()) + list(disp.parameters()), lr=1e-3, weight_decay=1e-8)
+    batch = synthetic_batch(2, 128, 416, seed=1234, device=DEV)
+    C.set_deterministic(True)
+    try:
+        arenas = []
+        for _ in range(3):
+            loss, _terms = unsupervise_losses(disp, pose, batch)
+            opt.zero_grad()
+            loss.backward()
+            opt.join_wgrad()
+            L.join_aux_streams()
+            torch.cuda.synchronize()
+            arenas.append(opt.flat_g.clone())
+    finally:
+        C.set_deterministic(False)
+    assert float(arenas[0].abs().max()) > 0
+    assert torch.equal(arenas[0], arenas[1]) and torch.equal(arenas[0], arenas[2])
