@@ -132,9 +132,11 @@ def build(args, cfg, device, world, rank):
     ddp = world > 1 or args.force_ddp
     params = [p for n in nets for p in n.parameters()]
     if cfg["body"] == "unsupervise":      # unsupervise.py:241  Adam(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)
-        opt = FlatAdam(params, lr=1e-3, weight_decay=1e-8, world_size=world, overlap=args.no_graph, always_reduce=ddp)
+        opt = FlatAdam(params, lr=1e-3, weight_decay=1e-8, world_size=world, overlap=args.no_graph, always_reduce=ddp,
+                       collective=getattr(args, "collective", "all_reduce"))
     else:                                 # train.py:150-156  Adam(lr=2e-4, betas=(0.9, 0.999), weight_decay=0)
-        opt = FlatAdam(params, lr=2e-4, weight_decay=0.0, world_size=world, overlap=args.no_graph, always_reduce=ddp)
+        opt = FlatAdam(params, lr=2e-4, weight_decay=0.0, world_size=world, overlap=args.no_graph, always_reduce=ddp,
+                       collective=getattr(args, "collective", "all_reduce"))
 
     def fwd_bwd():
         if cfg["body"] == "unsupervise":
@@ -276,6 +278,9 @@ def main():
     # default (neither flag, one GPU): both are built, each is timed for a few untimed steps, the faster one is used --
     # which of the two wins depends on how fast the host enqueues the ~360 launches of a step
     ap.add_argument("--force-ddp", action="store_true", help="run the multi-GPU exchange path even with one rank")
+    ap.add_argument("--collective", choices=("all_reduce", "rs_ag"), default="all_reduce",
+                    help="bucket exchange: one RCCL all-reduce, or reduce-scatter + all-gather in place (the direct all-links "
+                         "form of SURVEY section 8e) -- to be A/B'd on an 8-GPU node")
     ap.add_argument("--graph-ddp", action="store_true",
                     help="multi-GPU: replay forward+backward from a HIP graph and all-reduce afterwards (no overlap); "
                          "default for N>1 is eager launches with the all-reduce overlapped with backward")
@@ -377,8 +382,11 @@ def main():
 
     fence()
     t0 = time.perf_counter()
+    host = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         out = run()
+        host += time.perf_counter() - h0       # host time to ENQUEUE the step (no synchronisation inside run())
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -394,7 +402,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(5):
             for b in opt.buckets:
-                dist.all_reduce(opt.flat_g[b["start"]:b["end"]], op=dist.ReduceOp.SUM)
+                opt._exchange(b, opt.flat_g[b["start"]:b["end"]])
         fence()
         allreduce_ms = 1e3 * (time.perf_counter() - t1) / 5
 
@@ -409,9 +417,13 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "launch": ("hipgraph" if use_graph else "eager") + ("+rccl-allreduce" if ddp else "")},
             "final_loss": loss,
+            # host time spent enqueueing a step (Python + ctypes + launches, main thread; autograd's thread runs beside it):
+            # when it approaches ms_per_step the run is host-bound -- at N ranks on a shared CPU quota this is the number to watch
+            "host_enqueue_ms": 1e3 * host / args.steps,
         }
         if ddp:
             result["rccl_world_size"] = dist.get_world_size()
+            result["config"]["collective"] = opt.collective
             result["allreduce_ms_per_step"] = allreduce_ms
             result["allreduce_bytes_per_step"] = 4 * int(opt.total)
             result["allreduce_note"] = ("gradient arena in %d buckets, measured alone after the timed region; inside a step it "

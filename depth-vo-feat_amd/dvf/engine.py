@@ -22,7 +22,8 @@ class FlatAdam:
     """torch.optim.Adam over flat arenas.  ``params``: iterable of nn.Parameter (all nets together)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, world_size=1,
-                 bucket_mb=25.0, process_group=None, overlap=True, always_reduce=False, wgrad_stream=True, early_update=True):
+                 bucket_mb=25.0, process_group=None, overlap=True, always_reduce=False, wgrad_stream=True, early_update=True,
+                 collective="all_reduce"):
         """overlap=True: buckets are all-reduced on a side stream from inside backward (eager execution).
         overlap=False: backward only marks gradients; ``step()`` all-reduces the buckets on the current stream --
         the mode used when forward+backward are replayed from a HIP graph.  always_reduce: run the exchange even
@@ -32,6 +33,10 @@ class FlatAdam:
         weight copies of its layers -- while the rest of backward runs; ``step()`` only finishes what is left.  The
         deep layers hold most parameters and finish first, so nearly all of the optimizer's HBM streaming hides behind
         the (matrix-bound) backward of the shallow layers.
+        collective: how a bucket is exchanged -- "all_reduce" (one RCCL all-reduce: RCCL picks ring / tree / direct), or
+        "rs_ag" (reduce-scatter + all-gather in place: the direct all-links form of SURVEY section 8e, every GPU sends 1/world
+        of the bucket to each peer over its own xGMI link); the choice only changes which collectives run, not the result
+        layout, so an 8-GPU node can A/B the two in one run (bench.py --collective).
         wgrad_stream: weight-gradient kernels run on a second HIP stream.  Nothing in backward consumes a weight
         gradient, so they are off the critical path (dgrad chain) and fill the CUs that a single convolution kernel
         leaves idle; the streams join in ``join_wgrad()`` (called by ``step()``)."""
@@ -42,6 +47,10 @@ class FlatAdam:
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
         self.world_size, self.group = int(world_size), process_group
         self.overlap, self.exchange = bool(overlap), (int(world_size) > 1 or always_reduce)
+        if collective not in ("all_reduce", "rs_ag"):
+            raise ValueError("collective must be 'all_reduce' or 'rs_ag'")
+        self.collective = collective
+        self.exchange_log = None     # tests: set to a list() to record (bucket index, collective) of every exchange
         sizes = [p.numel() for p in self.params]
         # 64-float (256 B) aligned offsets: every view starts on its own cache lines
         self.offsets, off = [], 0
@@ -208,13 +217,28 @@ class FlatAdam:
         _conv.repack_all(owner=self, bucket=b["index"])
         b["updated"] = True
 
+    def _exchange(self, b, grads):
+        """Sum of the bucket's gradient slice over the ranks, in place."""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        n = grads.numel()
+        if self.collective == "rs_ag" and world > 1 and n % world == 0:
+            shard = grads[(n // world) * dist.get_rank(self.group):(n // world) * (dist.get_rank(self.group) + 1)]
+            dist.reduce_scatter_tensor(shard, grads, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(grads, shard, group=self.group)
+            kind = "rs_ag"
+        else:
+            dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
+            kind = "all_reduce"
+        self.n_reduced += 1
+        if self.exchange_log is not None:
+            self.exchange_log.append((b["index"], kind))
+
     def _launch_bucket(self, b):
         b["launched"] = True
         grads = self.flat_g[b["start"]:b["end"]]
         if self._comm_stream is None or L.SERIALIZE:        # CPU tensors (gloo), overlap=False or serialised: current stream
             if self.exchange:
-                dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
-                self.n_reduced += 1
+                self._exchange(b, grads)
             return
         # The bucket's gradients were written by kernels on EVERY compute stream of the step: bias gradients and thin
         # layers on the stream the layer's backward ran on (the main stream for the depth network, the auxiliary stream
@@ -231,8 +255,7 @@ class FlatAdam:
             comm.wait_stream(aux)
         with torch.cuda.stream(comm):
             if self.exchange:
-                dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
-                self.n_reduced += 1
+                self._exchange(b, grads)
             if self.early_update and self._ranges is not None:
                 self._adam_bucket(b)
 

@@ -4,7 +4,6 @@
   train_sfm_losses    train.py:179-203        4-scale photometric with masks + w3*smooth + stereo-pose MSE
 Each returns (total_loss, dict of detached per-term losses); the caller does zero_grad / backward / step.
 No ``.item()`` here: the reference's 5 host syncs per step (train.py:205-209) are left to the logger."""
-import os
 
 import torch
 
@@ -14,12 +13,16 @@ from dvf import lib as L
 from dvf.conv import reciprocal
 
 
+POSE_STREAM = True       # the pose network runs on the auxiliary stream beside the depth network
+
+
 def _side_by_side(aux_fn, main_fn):
     """Run two independent sub-networks concurrently: ``aux_fn`` (the small pose network) on a second stream, ``main_fn``
     (the depth network) on the current one.  The deep layers of either network launch fewer blocks than the GPU has
     CUs, so the two fill each other's gaps; autograd runs each backward on its forward stream, so the backward passes
-    overlap too.  FlatAdam.step() joins the auxiliary stream (dvf/lib.py AUX_STREAMS).  DVF_POSE_STREAM=0 disables."""
-    if L.SERIALIZE or os.environ.get("DVF_POSE_STREAM", "1") == "0":
+    overlap too.  FlatAdam.step() joins the auxiliary stream (dvf/lib.py AUX_STREAMS).  ``POSE_STREAM = False`` (module
+    attribute; tools set it, nothing on the product path reads the environment) puts both networks on one stream."""
+    if L.SERIALIZE or not POSE_STREAM:
         # same HOST order as below (depth network first): the order in which gradient buckets become ready -- and with it
         # the order of the all-reduce calls -- must not depend on this switch (bench.py times rank 0 serialised while the
         # other ranks run the overlapped schedule: mismatched collective orders would hang RCCL)

@@ -183,3 +183,73 @@ def test_weak_scaling_gradient_identity():
         halves.append(l)
     (sum(halves) / 2).backward()
     assert torch.allclose(depth.grad, g_full, rtol=1e-5, atol=1e-9)
+
+
+def _worker_mixed_schedule(rank, world, port, q):
+    """Rank 0 runs the one-stream schedule (L.SERIALIZE, as the kernel-timing pass of bench.py does), rank 1 the overlapped
+    one with its communication stream: the ORDER of the bucket exchanges is the order of the collective calls and must be
+    identical on both ranks (a mismatch deadlocks or silently mixes buckets).  The second phase
+    exchanges with reduce-scatter + all-gather instead of all-reduce: same sums."""
+    for p in (ROOT, PKG):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import contextlib
+        from dvf import lib as L
+        from dvf.engine import FlatAdam
+        out = {}
+        for collective in ("all_reduce", "rs_ag"):
+            torch.manual_seed(0)
+            params = [torch.nn.Parameter(torch.randn(n)) for n in (3008, 2944, 3072, 1024)]     # (64-float multiples: rs_ag splits evenly)
+            opt = FlatAdam(params, lr=1e-3, world_size=world, bucket_mb=0.01, collective=collective)
+            assert len(opt.buckets) >= 3
+            opt.exchange_log = []
+            if rank == 0:
+                L.SERIALIZE = True
+            else:
+                comm, main, cur = (_FakeStream(n) for n in ("comm", "main", "current"))
+                opt._comm_stream, opt._main_stream, opt._sides = comm, main, {}
+                torch.cuda.current_stream = lambda *a, **k: cur
+                torch.cuda.stream = lambda s: contextlib.nullcontext()
+            orders = []
+            for step in range(3):
+                opt.exchange_log.clear()
+                opt.zero_grad()
+                if rank == 1:
+                    opt._main_stream = main
+                for p in opt.params:
+                    p._dvf_grad.add_(float(rank + 1) * (step + 1))
+                    opt.grad_ready(p)
+                opt.synchronize_grads()
+                orders.append(list(opt.exchange_log))
+                for p in params:
+                    assert torch.allclose(p.grad, torch.full_like(p, 3.0 * (step + 1))), (collective, rank, step)
+            L.SERIALIZE = False
+            out[collective] = orders
+        gathered = [None, None]
+        dist.all_gather_object(gathered, out)
+        assert gathered[0] == gathered[1], gathered                       # same bucket order, same collective kind, every step
+        for collective, orders in gathered[0].items():
+            for step_order in orders:
+                assert [i for i, _ in step_order] == sorted(i for i, _ in step_order)          # arena (backward) order
+                assert all(kind == collective for _, kind in step_order), step_order
+        q.put((rank, "ok"))
+    except Exception as e:                                     # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e} | " + " / ".join(traceback.format_exc().splitlines()[-4:])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_serialized_and_overlapped_ranks_exchange_buckets_in_the_same_order_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mixed_schedule, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results

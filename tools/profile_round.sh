@@ -1,4 +1,4 @@
-# Profiles judged for the round (run on the GPU box through gpurun).  Outputs under gpurun_out/; tools/traffic.py, tools/db2stats.py
+# Profiles judged for the round (run on the GPU box through gpurun).  Outputs under gpurun_out/prof/; tools/traffic.py, tools/db2stats.py
 # and a few cp's turn them into profiles/<prefix>_*.
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof; rm -rf $O; mkdir -p $O
@@ -8,7 +8,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -
 echo "stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -o serial -- python3 $R/bench.py --steps 5 --warmup 2 --no-graph --serialize --no-cpu-baseline --no-kernel-timing > $O/bench_serial.json 2> $O/bench_serial.err
 echo "serial done"
-for c in 3 5; do
+for c in 3 4 5; do
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg$c -o cfg$c -- python3 $R/bench.py --config $c --steps 5 --warmup 2 --no-graph --serialize --no-cpu-baseline --no-kernel-timing > $O/bench_cfg${c}_serial.json 2> $O/bench_cfg${c}_serial.err
 done
 echo "cfg stats done"
