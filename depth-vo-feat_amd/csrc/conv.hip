@@ -1636,21 +1636,26 @@ static int dgrad_all(const dvf_conv_desc *d, const float *dpre, const float *pac
             rc = pipe_pack(op, nullptr, nullptr, &nf, nullptr, nullptr);      // plan only: is this segment packed?
             if (rc && rc != DVF_ERR_UNSUPPORTED) return rc;
         }
+        auto unpacked = [&]() -> int {
+            if (!din_segs[s]) return DVF_OK;
+            if (!w) return DVF_ERR_INVALID_ARG;
+            int done = 0;
+            int r = dgrad_segment_unpacked(d, dpre, w, din_segs[s], off, seg_channels[s], st, ws, ws_floats, nullptr,
+                                           mask_segs ? mask_segs[s] : nullptr, &done);
+            if (r) return r;
+            return done ? DVF_OK : postpass(s);
+        };
         if (rc == DVF_ERR_UNSUPPORTED) {                                      // narrow segment: unpacked kernels
-            if (din_segs[s]) {
-                if (!w) return DVF_ERR_INVALID_ARG;
-                int done = 0;
-                rc = dgrad_segment_unpacked(d, dpre, w, din_segs[s], off, seg_channels[s], st, ws, ws_floats, nullptr,
-                                            mask_segs ? mask_segs[s] : nullptr, &done);
-                if (rc) return rc;
-                if (!done) rc = postpass(s);
-                if (rc) return rc;
-            }
+            rc = unpacked();
+            if (rc) return rc;
         } else {
             if (din_segs[s]) {
                 op.a.mask = (mask_segs && mask_segs[s]) ? mask_segs[s] : nullptr;
                 op.a.dbias = (op.a.mask && dbias_segs) ? dbias_segs[s] : nullptr;
                 rc = pipe_run(op, packed, ws, ws_floats, st);
+                // refused at run time (an operand of a 16-byte-lane plan is not 16-byte aligned): this segment runs unpacked,
+                // masked or not -- the caller must not have to know which of its segments were packed
+                if (rc == DVF_ERR_UNSUPPORTED && w) rc = unpacked();
                 if (rc) return rc;
             }
             packed += nf;

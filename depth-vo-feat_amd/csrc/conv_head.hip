@@ -31,7 +31,7 @@ __device__ __forceinline__ void stage_tile(float *lds, const float *__restrict__
 // Weight addressing is general: w[m * ws_m + c * ws_c + tap'] with tap' = flip ? 8 - tap : tap, so the same kernel also
 // computes the dgrad of a narrow input segment (m = segment channel, c = output channel of the convolution, taps flipped).
 // Tile 64 x 8 pixels, two rows per thread; the per-thread staging offsets are channel-invariant.
-constexpr int FT_H = 8, FP_H = FT_H + 2, FP_N = FP_H * HP_W, F_LD = (FP_N + 255) / 256;
+constexpr int FT_H = 8;                    // tile rows of the full-resolution variant (head_fwd_kernel<.., 8, 8>)
 constexpr int HEAD_MAX_SEGS = 3;             // (the thin layers these kernels serve concatenate at most three tensors)
 struct HeadSegs {                            // the input: a virtual concat of up to HEAD_MAX_SEGS tensors
     const float *p[HEAD_MAX_SEGS];
@@ -102,7 +102,60 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadSegs in, const 
             }
         __syncthreads();
         if (sg2 < in.n) issue(sg2, cs2);
-        for (int ch = 0; ch < nch; ++ch) {
+        // (1-4 channel heads) four input channels in flight with their own accumulators: a thread's work is one long
+        // chain of LDS reads and dependent FMAs (288 per 32-channel round), and these layers run a block or less per CU
+        if constexpr (MO != 16) {
+            float part[3][ROWS][MO];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                    for (int m = 0; m < MO; ++m) part[q][r][m] = 0.f;
+            int ch = 0;
+            for (; ch + 4 <= nch; ch += 4) {
+                float v4[4][ROWS + 2][3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float *t = tile + (ch + q) * FPN + ly * HP_W + lx;
+#pragma unroll
+                    for (int a = 0; a < ROWS + 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) v4[q][a][b] = t[a * HP_W + b];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int m = 0; m < MO; ++m) {
+                        const float *wm = wsh + (m * C + cg + ch + q) * 9;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) {
+                            const float wk = wm[k];
+#pragma unroll
+                            for (int r = 0; r < ROWS; ++r) {
+                                if (q == 0) acc[r][m] = fmaf(wk, v4[q][k / 3 + r][k % 3], acc[r][m]);
+                                else part[q - 1][r][m] = fmaf(wk, v4[q][k / 3 + r][k % 3], part[q - 1][r][m]);
+                            }
+                        }
+                    }
+            }
+            for (; ch < nch; ++ch) {
+                const float *t = tile + ch * FPN + ly * HP_W + lx;
+#pragma unroll
+                for (int m = 0; m < MO; ++m) {
+                    const float *wm = wsh + (m * C + cg + ch) * 9;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+#pragma unroll
+                        for (int r = 0; r < ROWS; ++r) acc[r][m] = fmaf(wm[k], t[(k / 3 + r) * HP_W + k % 3], acc[r][m]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int m = 0; m < MO; ++m) acc[r][m] += (part[0][r][m] + part[1][r][m]) + part[2][r][m];
+        }
+        for (int ch = 0; ch < (MO == 16 ? nch : 0); ++ch) {
             const float *t = tile + ch * FPN + ly * HP_W + lx;
             float v[ROWS + 2][3];
 #pragma unroll

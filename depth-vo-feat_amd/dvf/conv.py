@@ -23,6 +23,10 @@ class _NullCtx:
         return False
 
 
+_NULL = _NullCtx()
+_NULL_PTRS = [(ctypes.c_void_p * max(n, 1))() for n in range(9)]    # all-NULL pointer tables by length
+
+
 def conv_out_size(h, k, stride, pad, opad, transposed):
     return (h - 1) * stride - 2 * pad + k + opad if transposed else (h + 2 * pad - k) // stride + 1
 
@@ -30,13 +34,13 @@ def conv_out_size(h, k, stride, pad, opad, transposed):
 _WS = {}      # (device, stream) -> split-K scratch shared by the convolutions of that stream
 
 
-def _workspace(nfloats, device):
+def _workspace(nfloats, device, raw_stream=None):
     """Scratch for split-K partial tiles: one buffer per compute stream (kernels of one stream are ordered, so they can
     share it); it only grows.  During a HIP-graph capture the current stream is the capture's own, so there is no
     cached buffer for it: the scratch then comes from the capture's private memory pool (one allocation per call, at
     capture time only) -- the captured step must run the same split-K reduction as the eager one, not the float-atomic
     fallback of a missing workspace."""
-    key = (device, L.stream().value)
+    key = (device, L.stream_raw() if raw_stream is None else raw_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
         if torch.cuda.is_current_stream_capturing():
@@ -124,17 +128,23 @@ def repack_all(owner=None, bucket=None):
         r[4][1] = _stamp(w)
 
 
-def _packed_weights(weight, holder, desc, segc, kind):
+def _packed_weights(weight, holder, desc, segc, kind, pkey=None, segarr=None):
     """Packed copy of `weight` for the pipelined kernels (kind 0: forward, 1: dgrad), cached on `holder` (the
     parameter) per layer geometry and refreshed when the weights changed.  None when the plan is unsupported."""
-    lib = L.lib()
-    cache = holder.__dict__.setdefault("_dvf_pack", {})
-    key = (kind, desc.N, desc.H_in, desc.W_in, desc.H_out, desc.W_out, desc.stride, desc.pad, desc.transposed, tuple(segc))
+    cache = holder.__dict__.get("_dvf_pack")
+    if cache is None:
+        cache = holder.__dict__["_dvf_pack"] = {}
+    if pkey is None:
+        pkey = (desc.N, desc.H_in, desc.W_in, desc.H_out, desc.W_out, desc.stride, desc.pad, desc.transposed, tuple(segc))
+    key = (kind, pkey)
     ent = cache.get(key)
     if ent is None:
-        nf = lib.dvf_conv2d_packed_floats(ctypes.byref(desc), L.int_array(segc), len(segc), kind)
+        lib = L.lib()
+        if segarr is None:
+            segarr = L.int_array(segc)
+        nf = lib.dvf_conv2d_packed_floats(ctypes.byref(desc), segarr, len(segc), kind)
         # split-K scratch of this op (packed and unpacked kernels alike): partial tiles are reduced in a fixed order
-        wsf = max(int(lib.dvf_conv2d_ws_floats(ctypes.byref(desc), L.int_array(segc), len(segc), kind)), 0)
+        wsf = max(int(lib.dvf_conv2d_ws_floats(ctypes.byref(desc), segarr, len(segc), kind)), 0)
         if nf == L.ERR_UNSUPPORTED:
             cache[key] = ent = [None, None, wsf]
         else:
@@ -146,11 +156,11 @@ def _packed_weights(weight, holder, desc, segc, kind):
     buf = ent[0]
     if buf is None:
         return None, (_workspace(ent[2], weight.device) if ent[2] else None)
-    stamp = _stamp(holder)
+    stamp = (holder.data_ptr(), holder._version, getattr(holder, "_dvf_epoch", 0), L.PACK_EPOCH)     # == _stamp(holder)
     if ent[1] != stamp:
         with L.timed("conv_pack", 0.0, 8.0 * weight.numel()):
-            L.check(lib.dvf_conv2d_pack(ctypes.byref(desc), L.int_array(segc), len(segc), kind, L.dev(weight, "weight"),
-                                        L.dev(buf), L.stream()), "dvf_conv2d_pack")
+            L.check(L.lib().dvf_conv2d_pack(ctypes.byref(desc), L.int_array(segc), len(segc), kind, L.dev(weight, "weight"),
+                                            L.dev(buf), L.stream()), "dvf_conv2d_pack")
         ent[1] = stamp
     return buf, (_workspace(ent[2], weight.device) if ent[2] else None)
 
@@ -199,6 +209,33 @@ class ReluTag:
     __slots__ = ()
 
 
+class _Geo:
+    """One layer geometry: descriptor, segment table and labels (built once per (cfg, N, H, W, segment channels))."""
+    __slots__ = ("desc", "dref", "segc", "segarr", "nseg", "cin0", "cout", "oh", "ow", "macs", "tag", "pkey")
+
+    def __init__(self, weight, cfg, inputs):
+        k, stride, pad, opad, transposed, act, alpha, beta, out_hw = cfg[:9]
+        N, _, H, W = inputs[0].shape
+        self.segc = segc = [int(x.shape[1]) for x in inputs]
+        self.nseg, self.cin0 = len(segc), segc[0]
+        self.segarr = L.int_array(segc)
+        cin = sum(segc)
+        self.cout = cout = weight.shape[1] if transposed else weight.shape[0]
+        if (weight.shape[0] if transposed else weight.shape[1]) != cin:
+            raise ValueError(f"weight {tuple(weight.shape)} does not match {cin} input channels")
+        oh, ow = conv_out_size(H, k, stride, pad, opad, transposed), conv_out_size(W, k, stride, pad, opad, transposed)
+        if out_hw is not None:                              # crop_like folded into the kernel
+            oh, ow = min(oh, out_hw[0]), min(ow, out_hw[1])
+        self.oh, self.ow = oh, ow
+        self.desc = L.ConvDesc(N, cin, H, W, cout, oh, ow, k, k, stride, pad, 1 if transposed else 0, act, alpha, beta)
+        self.dref = ctypes.byref(self.desc)
+        # algorithmic MACs of this layer (SURVEY.md section 8d): kept pixels x taps actually contributing
+        taps = k * k / (stride * stride) if transposed else k * k
+        self.macs = float(N) * cout * oh * ow * cin * taps
+        self.tag = f"{'T' if transposed else 'C'}{k}x{k}s{stride} {cin}->{cout} in{H}x{W} out{oh}x{ow} N{N}"
+        self.pkey = (N, H, W, oh, ow, stride, pad, 1 if transposed else 0, tuple(segc))
+
+
 class ConvFn(torch.autograd.Function):
     """act(conv(cat(inputs), weight) + bias).  cfg = (k, stride, pad, opad, transposed, act, alpha, beta, out_hw)."""
 
@@ -214,54 +251,66 @@ class ConvFn(torch.autograd.Function):
         inputs = [_c(x) for x in inputs]
         weight = _c(weight)
         bias = _c(bias) if bias is not None else None
-        N, _, H, W = inputs[0].shape
-        segc = [int(x.shape[1]) for x in inputs]
-        for x in inputs:
-            if x.shape[0] != N or x.shape[2] != H or x.shape[3] != W:
-                raise ValueError(f"virtual concat needs equal N,H,W; got {[tuple(t.shape) for t in inputs]}")
-        cin = sum(segc)
-        cout = weight.shape[1] if transposed else weight.shape[0]
-        if (weight.shape[0] if transposed else weight.shape[1]) != cin:
-            raise ValueError(f"weight {tuple(weight.shape)} does not match {cin} input channels")
-        oh, ow = conv_out_size(H, k, stride, pad, opad, transposed), conv_out_size(W, k, stride, pad, opad, transposed)
-        if out_hw is not None:                              # crop_like folded into the kernel
-            oh, ow = min(oh, out_hw[0]), min(ow, out_hw[1])
-        desc = L.ConvDesc(N, cin, H, W, cout, oh, ow, k, k, stride, pad, 1 if transposed else 0, act, alpha, beta)
+        x0 = inputs[0]
+        N, _, H, W = x0.shape
+        # everything that depends on the layer geometry alone (descriptor, sizes, labels) is made once per geometry and kept
+        # on the parameter: this function runs ~50 times per step and the host is the second bound of the step
+        gkey = (cfg[:9], N, H, W) if len(inputs) == 1 else (cfg[:9], N, H, W) + tuple(x.shape[1] for x in inputs[1:])
+        geos = ctx.holder.__dict__.get("_dvf_geo")
+        if geos is None:
+            geos = ctx.holder.__dict__["_dvf_geo"] = {}
+        g = geos.get(gkey)
+        if g is None:
+            g = geos[gkey] = _Geo(weight, cfg, inputs)
+        elif g.cin0 != x0.shape[1]:
+            raise ValueError(f"weight {tuple(weight.shape)} does not match {sum(int(x.shape[1]) for x in inputs)} input channels")
+        if g.nseg > 1:
+            for x in inputs:
+                if x.shape[0] != N or x.shape[2] != H or x.shape[3] != W:
+                    raise ValueError(f"virtual concat needs equal N,H,W; got {[tuple(t.shape) for t in inputs]}")
+        desc, segc, cout, oh, ow = g.desc, g.segc, g.cout, g.oh, g.ow
         if GEOM_LOG is not None:
             GEOM_LOG.append((tuple(segc), cout, tuple(cfg[:9]), (N, H, W), tuple(ctx.needs_input_grad[3:])))
         out = torch.empty((N, cout, oh, ow), device=weight.device, dtype=torch.float32)
-        # algorithmic MACs of this layer: kept pixels x taps actually contributing
-        taps = k * k / (stride * stride) if transposed else k * k
-        ctx.macs = float(N) * cout * oh * ow * cin * taps
-        ctx.tag = f"{'T' if transposed else 'C'}{k}x{k}s{stride} {cin}->{cout} in{H}x{W} out{oh}x{ow} N{N}"
-        packed, ws = _packed_weights(weight, ctx.holder, desc, segc, 0)
-        with L.timed("conv_fwd", 2 * ctx.macs, tag=ctx.tag):
+        ctx.macs, ctx.tag, ctx.geo = g.macs, g.tag, g
+        packed, ws = _packed_weights(weight, ctx.holder, desc, segc, 0, g.pkey, g.segarr)
+        # (operands went through _c(): float32 and contiguous; a CPU tensor is refused here, there is no CPU path)
+        if not x0.is_cuda:
+            L.dev(x0, "input")
+        inarr = (ctypes.c_void_p * g.nseg)(*[x.data_ptr() for x in inputs])
+        wsp, wsn = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
+        bp = bias.data_ptr() if bias is not None else None
+        lib = L.lib()
+        with (L.timed("conv_fwd", 2 * g.macs, tag=g.tag) if L.TIMER is not None else _NULL):
             rc = L.ERR_UNSUPPORTED
             if packed is not None:
-                rc = L.lib().dvf_conv2d_fwd_packed(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc),
-                                                   len(segc), L.dev(packed), L.dev(bias, "bias"), L.dev(out),
-                                                   L.dev(ws), ws.numel() if ws is not None else 0, L.stream())
-                if rc != L.ERR_UNSUPPORTED:             # (unsupported at run time: an operand is not 16-byte aligned)
+                rc = lib.dvf_conv2d_fwd_packed(g.dref, inarr, g.segarr, g.nseg, packed.data_ptr(), bp, out.data_ptr(),
+                                               wsp, wsn, L.stream_raw())
+                if rc != 0 and rc != L.ERR_UNSUPPORTED:     # (unsupported at run time: an operand is not 16-byte aligned)
                     L.check(rc, "dvf_conv2d_fwd_packed")
             if rc == L.ERR_UNSUPPORTED:
-                L.check(L.lib().dvf_conv2d_fwd_ws(ctypes.byref(desc), L.ptr_array(inputs, "input"), L.int_array(segc),
-                                                  len(segc), L.dev(weight, "weight"), L.dev(bias, "bias"), L.dev(out),
-                                                  L.dev(ws), ws.numel() if ws is not None else 0, L.stream()),
-                        "dvf_conv2d_fwd_ws")
-        L.note_plans("fwd")
+                rc = lib.dvf_conv2d_fwd_ws(g.dref, inarr, g.segarr, g.nseg, weight.data_ptr(), bp, out.data_ptr(), wsp, wsn,
+                                           L.stream_raw())
+                if rc != 0:
+                    L.check(rc, "dvf_conv2d_fwd_ws")
+        if L.PLAN_LOG is not None:
+            L.note_plans("fwd")
         ctx.save_for_backward(weight, out, *inputs)
-        ctx.desc, ctx.segc, ctx.has_bias = desc, segc, bias is not None
+        ctx.desc, ctx.segc, ctx.has_bias, ctx.inarr = desc, segc, bias is not None, inarr
         return out
 
     @staticmethod
     def backward(ctx, gout):
         weight, out, *inputs = ctx.saved_tensors
-        desc, segc = ctx.desc, ctx.segc
+        desc, segc, g = ctx.desc, ctx.segc, ctx.geo
         lib = L.lib()
         gout = _c(gout)
         N, cout, oh, ow = out.shape
-        need_w, need_b = ctx.needs_input_grad[0], ctx.has_bias and ctx.needs_input_grad[1]
-        need_in = list(ctx.needs_input_grad[3:])
+        nig = ctx.needs_input_grad
+        need_w, need_b = nig[0], ctx.has_bias and nig[1]
+        need_in = nig[3:]
+        timing = L.TIMER is not None
+        st = L.stream_raw()
         # a bias owned by a FlatAdam arena: its gradient slice is zero after zero_grad(), add the channel sums in place
         acc_b = need_b and ctx.bparam is not None
         dbias = (ctx.bparam._dvf_grad if acc_b else torch.empty(cout, device=out.device)) if need_b else None
@@ -272,58 +321,70 @@ class ConvFn(torch.autograd.Function):
             dpre = gout
         elif desc.act != L.ACT_NONE:
             dpre = torch.empty_like(gout)
-            with L.timed("act_bwd", 0.0, 12.0 * gout.numel()):
+            with (L.timed("act_bwd", 0.0, 12.0 * gout.numel()) if timing else _NULL):
                 _bias_sums(lib, gout, out, dpre, dbias, N, cout, oh * ow, desc.act, desc.alpha, desc.beta, acc_b)
         else:
             dpre = gout
             if need_b:
                 _bias_sums(lib, gout, None, None, dbias, N, cout, oh * ow, L.ACT_NONE, 1.0, 0.0, acc_b)
-        gins = [torch.empty_like(x) if need else None for x, need in zip(inputs, need_in)]
-        if any(need_in):
-            frac = sum(c for c, need in zip(segc, need_in) if need) / float(sum(segc))
-            packed, ws = _packed_weights(weight, ctx.holder, desc, segc, 1)
+        if not dpre.is_cuda:
+            L.dev(dpre, "grad_out")
+        dprep = dpre.data_ptr()
+        any_in = True in need_in
+        gins = [torch.empty_like(x) if need else None for x, need in zip(inputs, need_in)] if any_in else [None] * g.nseg
+        if any_in:
+            packed, ws = _packed_weights(weight, ctx.holder, desc, segc, 1, g.pkey, g.segarr)
+            wsp, wsn = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
+            pp = packed.data_ptr() if packed is not None else None
+            ginarr = (ctypes.c_void_p * g.nseg)(*[t.data_ptr() if t is not None else None for t in gins])
             masked = [t is not None and need for t, need in zip(ctx.in_tags, need_in)]
-            with L.timed("conv_dgrad", 2 * ctx.macs * frac, tag=ctx.tag):
-                if any(masked):
+            if timing:
+                frac = sum(c for c, need in zip(segc, need_in) if need) / float(sum(segc))
+            with (L.timed("conv_dgrad", 2 * g.macs * frac, tag=g.tag) if timing else _NULL):
+                if True in masked:
                     # segments produced by fuse_bwd ReLU layers: their gradient leaves masked, their bias gradient summed
-                    masks = [x if m else None for x, m in zip(inputs, masked)]
-                    dbs = [None] * len(masks)
-                    L.check(lib.dvf_conv2d_dgrad_masked(ctypes.byref(desc), L.dev(dpre), L.dev(packed), L.dev(weight),
-                                                        L.ptr_array(gins), L.int_array(segc), len(segc), L.dev(ws),
-                                                        ws.numel() if ws is not None else 0, L.ptr_array(masks),
-                                                        L.ptr_array(dbs), L.stream()), "dvf_conv2d_dgrad_masked")
+                    # (a segment whose packed plan is refused at run time runs unpacked inside the library)
+                    marr = (ctypes.c_void_p * g.nseg)(*[x.data_ptr() if m else None for x, m in zip(inputs, masked)])
+                    rc = lib.dvf_conv2d_dgrad_masked(g.dref, dprep, pp, weight.data_ptr(), ginarr, g.segarr, g.nseg, wsp, wsn,
+                                                     marr, _NULL_PTRS[g.nseg], st)
+                    if rc != 0:
+                        L.check(rc, "dvf_conv2d_dgrad_masked")
                 else:
                     rc = L.ERR_UNSUPPORTED
                     if packed is not None:
-                        rc = lib.dvf_conv2d_dgrad_packed(ctypes.byref(desc), L.dev(dpre), L.dev(packed), L.dev(weight),
-                                                         L.ptr_array(gins), L.int_array(segc), len(segc), L.dev(ws),
-                                                         ws.numel() if ws is not None else 0, L.stream())
-                        if rc != L.ERR_UNSUPPORTED:
+                        rc = lib.dvf_conv2d_dgrad_packed(g.dref, dprep, pp, weight.data_ptr(), ginarr, g.segarr, g.nseg, wsp, wsn, st)
+                        if rc != 0 and rc != L.ERR_UNSUPPORTED:
                             L.check(rc, "dvf_conv2d_dgrad_packed")
                     if rc == L.ERR_UNSUPPORTED:
-                        L.check(lib.dvf_conv2d_dgrad_ws(ctypes.byref(desc), L.dev(dpre), L.dev(weight), L.ptr_array(gins),
-                                                        L.int_array(segc), len(segc), L.dev(ws),
-                                                        ws.numel() if ws is not None else 0, L.stream()), "dvf_conv2d_dgrad_ws")
-            L.note_plans("dgrad")
+                        rc = lib.dvf_conv2d_dgrad_ws(g.dref, dprep, weight.data_ptr(), ginarr, g.segarr, g.nseg, wsp, wsn, st)
+                        if rc != 0:
+                            L.check(rc, "dvf_conv2d_dgrad_ws")
+            if L.PLAN_LOG is not None:
+                L.note_plans("dgrad")
         dw = None
         if fused_out and need_b and not need_w:     # (frozen weights, trainable bias: one reduction pass over dpre)
             _bias_sums(lib, dpre, None, None, dbias, N, cout, oh * ow, L.ACT_NONE, 1.0, 0.0, acc_b)
         if need_w:
             arena = ctx.wparam is not None
             dw = ctx.wparam._dvf_grad if arena else torch.empty_like(weight)
-            # with a FlatAdam arena the weight gradient is not consumed inside backward: run it on the side stream
+            # with a FlatAdam arena the weight gradient is not consumed inside backward: it goes to the side stream.  The
+            # launch names that stream by its handle (switching torch's current stream costs ~20 us of host time per layer);
+            # only the timing passes, whose events are recorded on the current stream, switch it.
             side = ctx.wparam._dvf_owner.fork_wgrad(dpre, *inputs) if arena else None
-            with (torch.cuda.stream(side) if side is not None else _NullCtx()):
-                with L.timed("conv_wgrad", 2 * ctx.macs, tag=ctx.tag):
+            wst = side._dvf_raw if side is not None else st
+            with (torch.cuda.stream(side) if (side is not None and timing) else _NULL):
+                with (L.timed("conv_wgrad", 2 * g.macs, tag=g.tag) if timing else _NULL):
                     # (DETERMINISTIC: partial tiles through a per-stream scratch, summed in fixed order; else float atomics)
                     wsf = _wgrad_ws_floats(ctx.wparam if arena else weight, desc, segc) if DETERMINISTIC else 0
-                    wws = _workspace(wsf, dpre.device) if wsf > 0 else None
-                    L.check(lib.dvf_conv2d_wgrad_det(ctypes.byref(desc), L.ptr_array(inputs), L.int_array(segc), len(segc),
-                                                     L.dev(dpre), L.dev(dw), 1 if arena else 0,
-                                                     L.dev(dbias) if (fused_out and need_b) else None, 1 if acc_b else 0,
-                                                     L.dev(wws), wws.numel() if wws is not None else 0, L.stream()),
-                            "dvf_conv2d_wgrad_det")
-                    L.note_plans("wgrad")
+                    wws = _workspace(wsf, dpre.device, wst) if wsf > 0 else None
+                    rc = lib.dvf_conv2d_wgrad_det(g.dref, ctx.inarr, g.segarr, g.nseg, dprep, dw.data_ptr(), 1 if arena else 0,
+                                                  dbias.data_ptr() if (fused_out and need_b) else None, 1 if acc_b else 0,
+                                                  wws.data_ptr() if wws is not None else None,
+                                                  wws.numel() if wws is not None else 0, wst)
+                    if rc != 0:
+                        L.check(rc, "dvf_conv2d_wgrad_det")
+                    if L.PLAN_LOG is not None:
+                        L.note_plans("wgrad")
             if arena:
                 ctx.wparam._dvf_owner.grad_ready(ctx.wparam)
                 dw = None

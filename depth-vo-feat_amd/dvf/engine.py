@@ -111,13 +111,14 @@ class FlatAdam:
         # (host cost matters: this runs once per convolution of the backward pass.  The raw stream handle keys a cache of
         # (stream object, side stream, ring of reusable events): a wait captures the event's state when it is enqueued, so
         # re-recording a ring slot later does not disturb an earlier wait.)
-        raw = L.stream().value
+        raw = L.stream_raw()
         ent = self._fork_cache.get(raw)
         if ent is None:
             cur = torch.cuda.current_stream()
             side = self._sides.get(cur.cuda_stream)
             if side is None:     # one per compute stream: a sub-network on the auxiliary stream gets its own
                 side = self._sides[cur.cuda_stream] = self.side if not self._sides else torch.cuda.Stream(device=cur.device)
+            side._dvf_raw = side.cuda_stream      # (ConvFn.backward launches on the side stream by handle)
             ent = self._fork_cache[raw] = [cur, side, [torch.cuda.Event() for _ in range(32)], 0]
         cur, side, ring, i = ent
         ent[3] = (i + 1) & 31

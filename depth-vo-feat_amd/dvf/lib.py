@@ -129,8 +129,16 @@ def stream():
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(_DEV_INDEX))
 
 
+def stream_raw():
+    """stream() as a plain integer (ctypes converts it for a void* parameter)."""
+    global _DEV_INDEX
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
+
+
 def dev(t, name="tensor"):
-    """Validate a tensor for the C ABI (cuda, fp32, contiguous) and return its device pointer."""
+    """Validate a tensor for the C ABI (cuda, fp32, contiguous) and return its device pointer (an integer; None for None)."""
     if t is None:
         return None
     if not t.is_cuda:
@@ -139,13 +147,14 @@ def dev(t, name="tensor"):
         raise TypeError(f"{name}: expected float32, got {t.dtype}")
     if not t.is_contiguous():
         raise RuntimeError(f"{name}: expected a contiguous tensor")
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 def ptr_array(tensors, name="tensors"):
     arr = (ctypes.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
-        arr[i] = None if t is None else dev(t, f"{name}[{i}]").value
+        if t is not None:
+            arr[i] = dev(t, name)
     return arr
 
 
