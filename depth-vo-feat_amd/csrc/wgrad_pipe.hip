@@ -278,7 +278,10 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
 #pragma unroll
             for (int r = 0; r < NACC; ++r) acc[m][u][r] = 0.f;
 
-    auto consume = [&](int st) {
+    // vy / vg: rows and pixel groups per row of the tile that lie inside the P grid.  The groups outside are zeros (the DMA's
+    // range check): on the 2x7 ... 4x13 maps of the deep layers they are 50-88 % of the tile, so the K loop runs over the
+    // valid groups only (an odd count is padded with one group of zeros).
+    auto consume = [&](int st, int vy, int vg) {
         const float *Pst = smem + st * stage_floats;
         const float *Qst = Pst + PF;
         const float *ap = Pst + ((nl >> 1) * WGP_PAIR + (nl & 1) * 128 + 4 * kh);
@@ -290,9 +293,11 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
         // group `it` = 4*KQ pixels of a tile row (8 with the 32-wide tiles, 16 with the 16-wide ones): lane (., kq) holds
         // pixels 4*kq .. 4*kq+3 of the group, MFMA step i multiplies component i of every kq
         constexpr int GP = 4 * KQ, GPR = WGP_BW / GP;          // pixels per group, groups per tile row
-        auto load = [&](auto bufc, int it) {
+        int ly = 0, ltq = 0;                                   // load iterator over the valid groups (scalar)
+        auto load = [&](auto bufc) {
             constexpr int buf = decltype(bufc)::value;
-            const int y = it / GPR, tq = it - y * GPR;
+            const int y = ly, tq = ltq;
+            if (++ltq == vg) { ltq = 0; ++ly; }
             const float *ay = ap + y * 32 + GP * tq;
 #pragma unroll
             for (int m = 0; m < MT; ++m) A[buf][m] = *reinterpret_cast<const f4 *>(ay + m * (TILE / 2) * WGP_PAIR);
@@ -320,12 +325,13 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
         };
         using B0 = std::integral_constant<int, 0>;
         using B1 = std::integral_constant<int, 1>;
-        constexpr int NG = WGP_BH * WGP_BW / GP;
-        load(B0{}, 0);
-        for (int it = 0; it < NG; it += 2) {
-            load(B1{}, it + 1);
+        static_assert(GPR * GP == WGP_BW, "groups tile a row");
+        const int NGv = vy * vg;                               // (past the last valid row the loads read rows of zeros / the next slot: unused)
+        load(B0{});
+        for (int it = 0; it < NGv; it += 2) {
+            load(B1{});
             mma(B0{});
-            if (it + 2 < NG) load(B0{}, it + 2);
+            if (it + 2 < NGv) load(B0{});
             mma(B1{});
         }
     };
@@ -384,14 +390,24 @@ __global__ __launch_bounds__(WGP_THREADS) void wgrad_pipe_kernel(const WgpArgs a
     if (DVF_DBG(a, 64)) return;
     unsigned long long t_loop0 = 0, t_loop1 = 0, tb0 = 0, tb1 = 0, tf0 = 0, tf1 = 0, w_bar = 0, w_flush = 0;
     DVF_STAMP(a, t_loop0);
+    int ctY, ctX;                          // tile coordinates of the current item inside its image
+    {
+        const int txy = a.tilesX * a.tilesY, r = tile % txy;
+        ctY = r / a.tilesX;
+        ctX = r - ctY * a.tilesX;
+    }
+    constexpr int GPX = 4 * (64 / TILE);   // pixels per MFMA group (consume())
     for (int x = 0; x < nitems; ++x) {
+        const int vy = min(WGP_BH, a.GH - ctY * WGP_BH);
+        const int vg = (min(WGP_BW, a.GW - ctX * WGP_BW) + GPX - 1) / GPX;
+        if (++ctX == a.tilesX) { ctX = 0; if (++ctY == a.tilesY) ctY = 0; }
         // item x has landed (its producers waited for it) and item x-1 is fully consumed.  No vmcnt wait here: the
         // atomics of a flush stay in flight across the barrier.
         DVF_STAMP(a, tb0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         DVF_STAMP(a, tb1);
         w_bar += tb1 - tb0;
-        if (!DVF_DBG(a, 4)) consume(x & 1);
+        if (!DVF_DBG(a, 4)) consume(x & 1, vy, vg);
         int mc_next = mc;
         if (++tile == a.ntiles) { tile = 0; ++mc_next; }
         if ((x == nitems - 1 || mc_next != mc) && !DVF_DBG(a, 128)) {

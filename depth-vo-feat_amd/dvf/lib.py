@@ -176,8 +176,15 @@ class KernelTimer:
     stream).  ``bench.py`` switches it on for one eager pass to measure per-kernel durations next to their
     algorithmic FLOPs / bytes; it is off (None) otherwise and costs nothing."""
 
+    FAMILY = {1: "pipe", 2: "gather", 3: "head", 4: "head", 5: "head", 6: "wgrad", 7: "head", 8: "wgrad_pipe", 9: "dconvt"}
+
     def __init__(self):
-        self.records = []       # (kind, start_event, stop_event, flops, bytes)
+        self.records = []       # (kind, start_event, stop_event, flops, bytes, tag, kernel family)
+        self._kernels = []      # per record: the kernel families the call launched, in launch order
+
+    def records_with_kernels(self):
+        torch.cuda.synchronize()
+        return [r + (list(k),) for r, k in zip(self.records, self._kernels)]
 
     def start(self):
         ev = torch.cuda.Event(enable_timing=True)
@@ -187,26 +194,39 @@ class KernelTimer:
     def stop(self, kind, start_ev, flops=0.0, nbytes=0.0, tag=""):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
-        self.records.append((kind, start_ev, ev, float(flops), float(nbytes), tag))
+        fam, kernels = "", ()
+        if kind.startswith("conv_"):
+            # which kernels the call launched (dvf_conv2d_last_plans): the kernel family with the most work names the call
+            buf = (ctypes.c_int * 96)()
+            n = lib().dvf_conv2d_last_plans(buf, 96)
+            fams = [self.FAMILY.get(buf[i], "other") for i in range(0, n, 12)]
+            fam = next((f for f in ("pipe", "wgrad_pipe", "gather", "wgrad", "dconvt", "head") if f in fams), "other")
+            kernels = tuple(fams)
+        self.records.append((kind, start_ev, ev, float(flops), float(nbytes), tag, fam))
+        self._kernels.append(kernels)
 
     def table(self):
         """Per-call rows (kind, tag, ms, TFLOP/s, GB/s), slowest first."""
         torch.cuda.synchronize()
         rows = []
-        for kind, a, b, fl, by, tag in self.records:
+        for kind, a, b, fl, by, tag, fam in self.records:
             ms = a.elapsed_time(b)
-            rows.append((ms, kind, tag, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0))
+            rows.append((ms, kind, (fam + " " if fam else "") + tag, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                         by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0))
         return sorted(rows, reverse=True)
 
     def summary(self):
+        """Totals per kind, and per "kind/family" for the convolution calls (family: the kernel that ran)."""
         torch.cuda.synchronize()
         out = {}
-        for kind, a, b, fl, by, _tag in self.records:
-            d = out.setdefault(kind, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-            d["calls"] += 1
-            d["ms"] += a.elapsed_time(b)
-            d["flops"] += fl
-            d["bytes"] += by
+        for kind, a, b, fl, by, _tag, fam in self.records:
+            ms = a.elapsed_time(b)
+            for key in ((kind, kind + "/" + fam) if fam else (kind,)):
+                d = out.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+                d["calls"] += 1
+                d["ms"] += ms
+                d["flops"] += fl
+                d["bytes"] += by
         return out
 
 

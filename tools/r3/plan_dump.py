@@ -17,7 +17,20 @@ LAYERS = [  # name, segs, cout, k, s, p, op, transposed, (N,H,W)
     ("conv1.2 7x7s1 32->32", [32], 32, 7, 1, 3, 0, 0, (4, 128, 416)),
     ("iconv2 65->32 @128x416", [32, 32, 1], 32, 3, 1, 1, 0, 0, (4, 128, 416)),
     ("iconv4 256->128 @32x104", [128, 128], 128, 3, 1, 1, 0, 0, (4, 32, 104)),
+    ("conv5.2 512->512 @8x26", [512], 512, 3, 1, 1, 0, 0, (4, 8, 26)),
+    ("conv6.0 3x3s2 512->512 @8x26", [512], 512, 3, 2, 1, 0, 0, (4, 8, 26)),
+    ("conv6.2 512->512 @4x13", [512], 512, 3, 1, 1, 0, 0, (4, 4, 13)),
+    ("conv7.0 3x3s2 512->512 @4x13", [512], 512, 3, 2, 1, 0, 0, (4, 4, 13)),
+    ("conv7.2 512->512 @2x7", [512], 512, 3, 1, 1, 0, 0, (4, 2, 7)),
+    ("upconv7 T3x3s2 512->512 @2x7", [512], 512, 3, 2, 1, 1, 1, (4, 2, 7)),
+    ("iconv7 1024->512 @4x13", [512, 512], 512, 3, 1, 1, 0, 0, (4, 4, 13)),
+    ("upconv6 T3x3s2 512->512 @4x13", [512], 512, 3, 2, 1, 1, 1, (4, 4, 13)),
+    ("pose conv6 3x3s2 256->256 @8x26", [256], 256, 3, 2, 1, 0, 0, (4, 8, 26)),
+    ("pose conv7 3x3s2 256->256 @4x13", [256], 256, 3, 2, 1, 0, 0, (4, 4, 13)),
 ]
+if len(sys.argv) > 1:
+    LAYERS = [l for l in LAYERS if any(a in l[0] for a in sys.argv[1:])]
+WSF = 1 << 26      # pretend split-K scratch (planning only)
 for name, segs, cout, k, s, p, op, tr, (n, h, w) in LAYERS:
     if tr: oh, ow = (h - 1) * s - 2 * p + k + op, (w - 1) * s - 2 * p + k + op
     else: oh, ow = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
@@ -30,6 +43,6 @@ for name, segs, cout, k, s, p, op, tr, (n, h, w) in LAYERS:
         sys.stdout.flush()
         if kind == 0:
             lib.dvf_conv2d_fwd_packed.restype = ctypes.c_int
-            rc = lib.dvf_conv2d_fwd_packed(ctypes.byref(d), ins, segc, len(segs), ctypes.c_void_p(fake), ctypes.c_void_p(fake + 256), ctypes.c_void_p(fake + 4096), ctypes.c_void_p(0), ctypes.c_int64(0), ctypes.c_void_p(0))
+            rc = lib.dvf_conv2d_fwd_packed(ctypes.byref(d), ins, segc, len(segs), ctypes.c_void_p(fake), ctypes.c_void_p(fake + 256), ctypes.c_void_p(fake + 4096), ctypes.c_void_p(fake + (1 << 34)), ctypes.c_int64(WSF), ctypes.c_void_p(0))
         else:
-            rc = lib.dvf_conv2d_dgrad_packed(ctypes.byref(d), ctypes.c_void_p(fake), ctypes.c_void_p(fake + 4096), ctypes.c_void_p(fake + 8192), ins, segc, len(segs), ctypes.c_void_p(0), ctypes.c_int64(0), ctypes.c_void_p(0))
+            rc = lib.dvf_conv2d_dgrad_packed(ctypes.byref(d), ctypes.c_void_p(fake), ctypes.c_void_p(fake + 4096), ctypes.c_void_p(fake + 8192), ins, segc, len(segs), ctypes.c_void_p(fake + (1 << 34)), ctypes.c_int64(WSF), ctypes.c_void_p(0))
