@@ -981,6 +981,7 @@ int make_fwd_op(const dvf_conv_desc *d, const float *const *in_segs, const int *
     a.N = d->N; a.IH = d->H_in; a.IW = d->W_in; a.OH = d->H_out; a.OW = d->W_out;
     a.act = d->act; a.alpha = d->alpha; a.beta = d->beta;
     op.KK = d->KH * d->KW; op.m_base = 0; op.Mtot = d->C_out; op.Rtot = d->C_in;
+    op.head_fwd = !dvf_head_fwd_applicable(d, nseg) && dvf_head_applicable(d, nseg);
     if (!d->transposed) {
         op.w_mode = 0; op.ncls = 1; op.covers = true;
         op.cls[0] = ClassSpec{1, 0, 0, d->stride, -d->pad, -d->pad, d->KH, d->KW, d->H_out, d->W_out, {0}};
@@ -1000,6 +1001,7 @@ int make_dgrad_op(const dvf_conv_desc *d, const float *dpre, float *din, int off
     a.N = d->N; a.IH = d->H_out; a.IW = d->W_out; a.OH = d->H_in; a.OW = d->W_in;
     a.act = DVF_ACT_NONE;
     op.KK = d->KH * d->KW; op.m_base = off; op.Mtot = d->C_in; op.Rtot = d->C_out;
+    op.head_fwd = false;
     if (!d->transposed) {
         op.w_mode = 1;
         op.ncls = scatter_classes(d->stride, d->pad, d->KH, d->KW, d->H_in, d->W_in, op.cls, &op.covers);
@@ -1027,7 +1029,7 @@ int fwd_unpacked(const dvf_conv_desc *d, const float *const *in_segs, const int 
     if (rc) return rc;
     if (!ws_need && (!in_segs || !w || !out)) return DVF_ERR_INVALID_ARG;
     if (ws_need) *ws_need = 0;
-    if (dvf_head_applicable(d, nseg)) {
+    if (dvf_head_applicable(d, nseg)) {      // (every head: this is the unpacked route -- the wide ones normally arrive packed)
         if (ws_need) return DVF_OK;
         if (!in_segs[0]) return DVF_ERR_INVALID_ARG;
         return dvf_head_fwd(d, in_segs[0], w, bias, out, dvf_stream(stream));
@@ -1237,7 +1239,7 @@ int dvf_conv2d_dgrad_ws(const dvf_conv_desc *d, const float *dpre, const float *
     rc = check_segs(d, seg_channels, nseg);
     if (rc) return rc;
     if (!dpre || !w || !din_segs) return DVF_ERR_INVALID_ARG;
-    if (dvf_head_applicable(d, nseg)) return din_segs[0] ? dvf_head_dgrad(d, dpre, w, din_segs[0], dvf_stream(stream)) : DVF_OK;
+    if (dvf_head_applicable(d, nseg)) return din_segs[0] ? dvf_head_dgrad(d, dpre, w, din_segs[0], dvf_stream(stream)) : DVF_OK;   // (unpacked route)
     int off = 0;
     for (int s = 0; s < nseg; ++s) {
         const int segc = seg_channels[s];
@@ -1620,7 +1622,7 @@ static int dgrad_all(const dvf_conv_desc *d, const float *dpre, const float *pac
         return dvf_act_bwd2(din_segs[s], mask_segs[s], din_segs[s], dbias_segs ? dbias_segs[s] : nullptr, d->N, seg_channels[s],
                             HWin, DVF_ACT_RELU, 1.f, 0.f, 1, st);
     };
-    if (dvf_head_applicable(d, nseg)) {
+    if (dvf_head_dgrad_applicable(d, nseg) || (dvf_head_applicable(d, nseg) && !packed)) {
         if (!din_segs[0]) return DVF_OK;
         if (!w) return DVF_ERR_INVALID_ARG;
         return dvf_head_dgrad(d, dpre, w, din_segs[0], st, mask_segs ? mask_segs[0] : nullptr);     // (mask applied in the kernel)
@@ -1674,7 +1676,7 @@ int dvf_conv2d_dgrad_packed(const dvf_conv_desc *d, const float *dpre, const flo
     rc = check_segs(d, seg_channels, nseg);
     if (rc) return rc;
     if (!dpre || !packed || !din_segs) return DVF_ERR_INVALID_ARG;
-    if (dvf_head_applicable(d, nseg)) return DVF_ERR_UNSUPPORTED;
+    if (dvf_head_dgrad_applicable(d, nseg)) return DVF_ERR_UNSUPPORTED;
     return dgrad_all(d, dpre, packed, w, din_segs, seg_channels, nseg, ws, ws_floats, nullptr, nullptr, dvf_stream(stream));
 }
 

@@ -1,7 +1,9 @@
 // Direct kernels for 1-4 channel 3x3 heads (conv_head.hip), dispatched from the dvf_conv2d_* entries.
 #pragma once
 #include "dvf_common.h"
-bool dvf_head_applicable(const dvf_conv_desc *d, int nseg);
+bool dvf_head_applicable(const dvf_conv_desc *d, int nseg);          // geometry of a 1-4 channel 3x3 head (weight gradient)
+bool dvf_head_fwd_applicable(const dvf_conv_desc *d, int nseg);      // ... and the direct forward kernel is the faster one
+bool dvf_head_dgrad_applicable(const dvf_conv_desc *d, int nseg);    // ... and the direct dgrad kernel is the faster one
 int dvf_head_fwd(const dvf_conv_desc *d, const float *in, const float *w, const float *bias, float *out, hipStream_t st);
 bool dvf_head_wide_applicable(const dvf_conv_desc *d, int nseg);
 int dvf_head_fwd_segs(const dvf_conv_desc *d, const float *const *in_segs, const int *seg_channels, int nseg, const float *w,

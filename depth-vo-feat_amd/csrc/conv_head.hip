@@ -430,6 +430,20 @@ bool dvf_head_applicable(const dvf_conv_desc *d, int nseg) {
            d->C_out <= 4 && d->H_out == d->H_in && d->W_out == d->W_in && d->C_in >= 4 && d->C_in * d->C_out <= 1024 &&
            dvf_tune("DVF_NO_HEAD") == nullptr;
 }
+// Per role (round 3, rocprofv3 durations per layer, profiles/r03_launch_table.txt): the direct kernels are a chain of
+// per-channel LDS round trips per block, so the heads with many input channels on small maps (128 @32x104, 64 @64x208: a
+// few dozen blocks) lose to conv_pipe_kernel even with 94-97 % of its MFMA rows padding:
+//   forward 128->2 @32x104   46 us direct            dgrad 128->1 @32x104   48 us direct, 18 us conv_pipe
+//                                                    dgrad  64->1 @64x208   28 us direct, 18 us conv_pipe
+// The weight gradient stays direct at every size (13-58 us against 22-73 us).
+bool dvf_head_fwd_applicable(const dvf_conv_desc *d, int nseg) {
+    static const int maxc = dvf_tune("DVF_HEAD_FWD_MAXC") ? atoi(dvf_tune("DVF_HEAD_FWD_MAXC")) : 127;      // tuning knob
+    return dvf_head_applicable(d, nseg) && d->C_in <= maxc;
+}
+bool dvf_head_dgrad_applicable(const dvf_conv_desc *d, int nseg) {
+    static const int maxc = dvf_tune("DVF_HEAD_DGRAD_MAXC") ? atoi(dvf_tune("DVF_HEAD_DGRAD_MAXC")) : 32;   // tuning knob
+    return dvf_head_applicable(d, nseg) && d->C_in <= maxc;
+}
 
 bool dvf_dconvt_applicable(const dvf_conv_desc *d, int nseg) {
     const bool k3 = d->KH == 3 && d->KW == 3, k4 = d->KH == 4 && d->KW == 4;

@@ -74,7 +74,7 @@ struct PipeArgs {
     int64_t ws_slice;
     int lsw, lsh, TGX, TGY, BW, BH, BN, tilesX, tilesY;
     int x4;                               // patch DMA in 16-byte lanes (see pipe_geo)
-    int blk;                              // blocked accumulation (BLK = 1 instantiation)
+    int blk;                              // blocked accumulation: the accumulators are banked every blk chunks (0: never)
     int SLmax, PSRmax, NST;               // LDS carve per stage (NST = 2 or 3 stages): SLmax weight floats | CK * PSRmax patch floats
     int dbg;                              // ablation switches (tools/conv_bench.py): 1 no patch loads, 2 no weight loads, 4 no MFMA
     unsigned long long *stamps;           // -DDVF_TUNING builds: per-block cycle account (8 x u64 per block), or NULL
@@ -144,12 +144,12 @@ constexpr int PIPE_THREADS = 384;        // 4 MFMA waves + 2 producers; PIPE_THR
 constexpr int PIPE_THREADS_4P = 512;
 constexpr int PIPE_MAXNPI = 32;    // patch pieces per channel (per-channel patch <= 2048 floats)
 
-// BLK = 1: blocked accumulation -- the accumulators are added into a second register set and cleared after every chunk,
-// so a long reduction (K = channels x taps of 2304 and more) is a sum of per-chunk partial sums like a blocked CPU GEMM's
-// instead of one sequential fmaf chain (round 2's full-step gradients were up to 5.8x further from fp64 than the CPU
-// reference's in the deep layers for that reason).  +16*MT*NT VGPRs: one 8-wave block per CU, which is what those layers
-// run anyway.
-template <int MT, int NT, int WM, int CKH, int TBU, int BLK = 0>
+// Blocked accumulation (PipeArgs::blk = n > 0): every n chunks the accumulators are added into a second register set and
+// cleared, so a long reduction (K = channels x taps of 1152 and more) is a sum of partial sums over ~150-300 terms like a
+// blocked CPU GEMM's instead of one sequential fmaf chain (a 1161-term chain is 2.6x further from fp64 than torch's CPU
+// kernels, tools/r3/layer_noise.py; the full-step gradients were up to 5.8x further in round 2).  The second set costs no
+// occupancy: the kernel's register count is set by the producer waves' offset tables (141-155 VGPRs in every variant).
+template <int MT, int NT, int WM, int CKH, int TBU>
 __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeArgs a) {
     constexpr int CK = 2 * CKH, VW = CKH >= 4 ? 4 : CKH, CPG = CKH / VW, MTW = MT * WM;
     constexpr int UNITF = TBU * MTW * 64 * VW;             // packed floats per unit
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
         for (int j = 0; j < VW; ++j) bj[i][j] = bbase + j * 2 * PSR;
     }
     f32x16 acc[MT][NT];
-    f32x16 asum[BLK ? MT : 1][BLK ? NT : 1];              // (BLK) running sum of the per-chunk partial sums
+    f32x16 asum[MT][NT];                                   // (a.blk) running sum of the banked partial sums
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[m][i][r] = 0.f;
-                if constexpr (BLK) asum[m][i][r] = 0.f;
+                asum[m][i][r] = 0.f;
             }
 
     // The chunk in stage `st`, unit by unit.  A unit is one kernel ROW (ta) x VW channel pairs: its TBU taps are
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
     unsigned long long t_loop0 = 0, t_loop1 = 0, tb0 = 0, tb1 = 0, w_bar = 0;
     DVF_STAMP(a, t_loop0);
     if (!DVF_DBG(a, 8)) {
-        int st = 0;
+        int st = 0, since = 0;
         for (int g = g_begin; g < g_end; ++g) {
             DVF_STAMP(a, tb0);
             __syncthreads();          // chunk g has landed (its producer waited for it) and chunk g-1 is fully consumed
@@ -538,7 +538,8 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
                 if (a.IS == 2 && !a.x4) consume(st, std::integral_constant<int, 2>{});      // (de-interleaved rows)
                 else consume(st, std::integral_constant<int, 1>{});
             }
-            if constexpr (BLK) {
+            if (++since == a.blk) {     // (uniform; a.blk == 0: never)
+                since = 0;
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -551,11 +552,11 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
             st = (st + 1 == a.NST) ? 0 : st + 1;
         }
     }
-    if constexpr (BLK) {
+    if (a.blk) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int i = 0; i < NT; ++i) acc[m][i] = asum[m][i];
+            for (int i = 0; i < NT; ++i) acc[m][i] += asum[m][i];
     }
 
     DVF_STAMP(a, t_loop1);
@@ -692,31 +693,17 @@ template <int MT, int NT, int WM>
 int launch_pipe_family(const PipeArgs &a, int CKH, int TBU, dim3 grid, size_t lds, hipStream_t st, int threads);
 
 // blocks that use more than 64 KiB of LDS need the opt-in attribute (set once per kernel)
-// (the blocked-accumulation variant exists for the shapes whose reductions are long: 64-channel waves, 2- to 4-tap rows,
-// 8- or 16-channel chunks; the planner asks for it only there)
 template <int MT, int NT, int WM, int CKH, int TBU>
-constexpr bool pipe_has_blk() { return MT == 2 && NT == 1 && WM == 1 && CKH >= 4 && TBU >= 2 && TBU <= 4; }
-
-template <int MT, int NT, int WM, int CKH, int TBU, int BLK>
-inline int launch_pipe_blk(const PipeArgs &a, dim3 grid, size_t lds, hipStream_t st, int threads) {
+inline int launch_pipe_one(const PipeArgs &a, dim3 grid, size_t lds, hipStream_t st, int threads) {
     static bool big_lds = false;
     if (lds > 64 * 1024 && !big_lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pipe_kernel<MT, NT, WM, CKH, TBU, BLK>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pipe_kernel<MT, NT, WM, CKH, TBU>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return DVF_ERR_LAUNCH;
         big_lds = true;
     }
-    conv_pipe_kernel<MT, NT, WM, CKH, TBU, BLK><<<grid, threads, lds, st>>>(a);
+    conv_pipe_kernel<MT, NT, WM, CKH, TBU><<<grid, threads, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? DVF_OK : DVF_ERR_LAUNCH;
-}
-
-template <int MT, int NT, int WM, int CKH, int TBU>
-inline int launch_pipe_one(const PipeArgs &a, dim3 grid, size_t lds, hipStream_t st, int threads) {
-    if (a.blk) {
-        if constexpr (pipe_has_blk<MT, NT, WM, CKH, TBU>()) return launch_pipe_blk<MT, NT, WM, CKH, TBU, 1>(a, grid, lds, st, threads);
-        else return DVF_ERR_UNSUPPORTED;
-    }
-    return launch_pipe_blk<MT, NT, WM, CKH, TBU, 0>(a, grid, lds, st, threads);
 }
 
 template <int MT, int NT, int WM, int CKH>

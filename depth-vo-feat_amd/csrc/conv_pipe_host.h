@@ -285,7 +285,7 @@ inline PipeTiles pipe_tiles(int OHc, int OWc, int N, int ntile, int BNwant, int 
 
 
 // Plan one op (all its classes share the launch).  Fills `a`'s tiling/packing fields; the same plan drives packing.
-int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
+int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl, bool head_fwd = false) {
     if (ncls < 1 || ncls > 4) return DVF_ERR_INVALID_ARG;
     a.ncls = ncls; a.OS = cls[0].OS; a.IS = cls[0].IS;
     int Tmax = 0, TAmax = 0, TBmax = 0, OHc = 0, OWc = 0;
@@ -301,7 +301,13 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
     // be padding); 17..32 channels run here since round 3 (with the rewritten producers the pipelined kernel wins for the 3x3
     // layers too: 3x3 65->32 @128x416 forward 0.143 -> 0.121 ms in the step).
     static const int smallm = dvf_tune("DVF_PIPE_SMALLM") ? atoi(dvf_tune("DVF_PIPE_SMALLM")) : 0;      // tuning knob
-    const bool small_ok = a.M > 16 || ((smallm & 1) && a.M <= 16 && ncls > 1) ||
+    // ... except the 1-4 channel heads over >= 128 input channels (K >= 1152 on a 32x104 map: the direct kernel is a chain of
+    // 128 per-channel LDS round trips on 64 blocks -- 36-46 us -- against ~1 GFLOP of mostly-padding MFMA work here)
+    int ctot = 0;
+    for (int s = 0; s < a.nseg; ++s) ctot += a.segC[s];
+    static const int headc = dvf_tune("DVF_PIPE_HEADC") ? atoi(dvf_tune("DVF_PIPE_HEADC")) : 128;       // tuning knob
+    const bool wide_head = head_fwd && a.M <= 4 && ncls == 1 && ctot >= headc && Tmax == 9;
+    const bool small_ok = a.M > 16 || wide_head || ((smallm & 1) && a.M <= 16 && ncls > 1) ||
                           ((smallm & 2) && a.M <= 16) || ((smallm & 4) && a.M > 16);
     if (a.M <= 32 && !ov.on && !small_ok) return DVF_ERR_UNSUPPORTED;
     if (ov.on && ov.KS < 0) return DVF_ERR_UNSUPPORTED;      // (tuning: force the gather kernel)
@@ -422,14 +428,25 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl) {
         if ((int64_t)a.N * a.segC[s2] * a.IH * a.IW * 4 >= ((int64_t)1 << 31) - 16) return DVF_ERR_UNSUPPORTED;
     pl.MT = MT; pl.NT = NT; pl.WM = WM; pl.CKH = CK / 2; pl.TBU = TBU; pl.lds = dd.lds;
     pl.grid = dim3(a.tilesX * a.tilesY, mblocks, a.NG * KS * ncls);
-    // blocked accumulation (conv_pipe.h, BLK): reductions of 512 and more terms per block (channels x taps of its K range),
-    // on grids that give a block a CU to itself anyway (the variant needs the registers of two waves per SIMD)
+    // Blocked accumulation (conv_pipe.h): the accumulators are banked every `blk` chunks.  Product policy = round 2/3's: every
+    // chunk, in the deep layers only (64-channel waves, 8/16-channel chunks of 2-4-tap rows, a K range of >= 512 terms on a
+    // block that owns its CU) -- the layers whose sequential 2304-9216-term chains were up to 5.8x further from fp64 than the
+    // CPU reference.  Banking EVERYWHERE (~96 terms apart: tuning knob DVF_PIPE_BLKT) brings every layer's rms error to
+    // 1.4e-7, below torch's CPU kernels (1.7e-7; iconv3's unblocked 1161-term chain: 4.3e-7), but it also moves the results
+    // AWAY from the reference's own rounding: torch's CPU convolution accumulates K sequentially, the unblocked kernels
+    // reproduce its cfg-1 gradients to 2e-5 where the blocked ones differ by the fp32 noise floor (1e-4 in the deep layers),
+    // which flips the sign of 162 of 12 M first Adam steps and moves the second iteration's loss by 0.5 % (tools/r3/
+    // cfg1_flips.py, profiles/r03_blocked_accumulation.txt).  Parity with the reference wins; the knob stays in the tuning build.
     {
-        const int64_t kseq = (int64_t)cdiv(a.NCH, KS) * CK * TAmax * TBmax;
-        static const int blk_knob = dvf_tune("DVF_PIPE_BLK") ? atoi(dvf_tune("DVF_PIPE_BLK")) : -1;     // tuning: 0 off, 1 wherever built
-        const bool built = MT == 2 && NT == 1 && WM == 1 && CK >= 8 && TBU >= 2 && TBU <= 4;
-        const bool whole_cu = (int64_t)pl.grid.x * pl.grid.y * pl.grid.z <= 256 || pl.lds > 76 * 1024;
-        a.blk = (built && whole_cu && (blk_knob == 1 || (blk_knob != 0 && kseq >= 512))) ? 1 : 0;
+        const int per_chunk = CK * TAmax * TBmax;
+        const int64_t kseq = (int64_t)cdiv(a.NCH, KS) * per_chunk;
+        static const int blk_knob = dvf_tune("DVF_PIPE_BLK") ? atoi(dvf_tune("DVF_PIPE_BLK")) : -1;     // tuning: 0 off, n: every n chunks
+        static const int blk_terms = dvf_tune("DVF_PIPE_BLKT") ? atoi(dvf_tune("DVF_PIPE_BLKT")) : 0;   // tuning: terms per bank, all layers
+        const bool deep = MT == 2 && NT == 1 && WM == 1 && CK >= 8 && TBU >= 2 && TBU <= 4 && kseq >= 512 &&
+                          ((int64_t)pl.grid.x * pl.grid.y * pl.grid.z <= 256 || pl.lds > 76 * 1024);
+        int every = blk_terms > 0 ? (blk_terms + per_chunk / 2) / per_chunk : 1;
+        if (every < 1) every = 1;
+        a.blk = blk_knob == 0 ? 0 : blk_knob > 0 ? blk_knob : blk_terms > 0 ? (kseq >= 384 ? every : 0) : (deep ? 1 : 0);
     }
     // a block that has a CU to itself (by LDS size or by grid size) gets four producer waves, one per SIMD
     {
@@ -462,13 +479,14 @@ struct PipeOp {
     int ncls;
     bool covers;
     int w_mode, Mtot, Rtot, KK, m_base;
+    bool head_fwd;       // forward of a Conv2d (make_fwd_op): the 1-4 channel heads over >= 128 channels may run here
 };
 
 // ws: optional split-K workspace (ws_floats floats).  With it the K-splits store plain partial tiles and one pass
 // reduces them (+bias, activation); without it they accumulate with float atomics into a zeroed output.
 int pipe_run(PipeOp &op, const float *packed, float *ws, int64_t ws_floats, hipStream_t st) {
     PipePlan pl;
-    int rc = plan_pipe(op.a, op.cls, op.ncls, pl);
+    int rc = plan_pipe(op.a, op.cls, op.ncls, pl, op.head_fwd);
     if (rc) return rc;
     PipeArgs &a = op.a;
     a.wp = packed;
@@ -496,7 +514,7 @@ int pipe_run(PipeOp &op, const float *packed, float *ws, int64_t ws_floats, hipS
     if (a.x4)
         for (int s2 = 0; s2 < a.nseg; ++s2)
             if (reinterpret_cast<uintptr_t>(a.in[s2]) & 15) return DVF_ERR_UNSUPPORTED;    // (a view at an odd element offset)
-    dvf_plan_note(DVF_K_PIPE, pl.MT, pl.NT, pl.WM, 2 * pl.CKH, pl.TBU, a.KS, a.BN, a.NST, pl.threads, (int)pl.lds, mode | (a.ncls << 4) | (a.x4 << 8) | (a.blk << 9));
+    dvf_plan_note(DVF_K_PIPE, pl.MT, pl.NT, pl.WM, 2 * pl.CKH, pl.TBU, a.KS, a.BN, a.NST, pl.threads, (int)pl.lds, mode | (a.ncls << 4) | (a.x4 << 8) | ((a.blk ? 1 : 0) << 9));
     if (dvf_tune("DVF_PIPE_DEBUG"))
         fprintf(stderr, "[pipe] M %d chunks %d N %d out %dx%d cls %d | MT %d NT %d WM %d CK %d TBU %d KS %d BN %d tile %dx%d "
                 "(sub %dx%d) grid %ux%ux%u lds %zu x%d mode %d\n", a.M, a.NCH, a.N, a.OH, a.OW, a.ncls, pl.MT, pl.NT, pl.WM,
@@ -530,7 +548,7 @@ int pipe_run(PipeOp &op, const float *packed, float *ws, int64_t ws_floats, hipS
 int pipe_pack(PipeOp &op, const float *w, float *packed, int64_t *nfloats, int64_t *wsfloats, hipStream_t st,
               PackArgs *job_out = nullptr, int *job_blocks = nullptr) {
     PipePlan pl;
-    int rc = plan_pipe(op.a, op.cls, op.ncls, pl);
+    int rc = plan_pipe(op.a, op.cls, op.ncls, pl, op.head_fwd);
     if (rc) return rc;
     if ((size_t)32 * ((2 * pl.CKH * op.KK) | 1) * sizeof(float) > 64 * 1024) return DVF_ERR_UNSUPPORTED;   // pack kernel's LDS tile
     if (nfloats) *nfloats = pl.packed_floats;

@@ -73,7 +73,7 @@ def test_posenet_golden(tag):
 def _check_params(g, name, module, sd0, lr, n_steps=2):
     """Post-Adam parameters vs the reference run (see tests/test_oracle_golden.py::_check_params): small tensors
     element by element, large ones by norm at 1e-4, and
-    the UPDATE p - p0 by norm (1e-3) and by sum (1e-3 of its norm + 2*lr*n_steps*(4 + 1e-4*numel) for sign flips of
+    the UPDATE p - p0 by norm (1e-3) and by sum (1e-3 of its norm + 2*lr*n_steps*(4 + 2e-4*numel) for sign flips of
     noise-level gradients)."""
     sd = {k: v.detach().double().cpu() for k, v in module.state_dict().items()}
     keys = [str(k) for k in g[f"p_{name}_keys"]]
@@ -95,7 +95,11 @@ def _check_params(g, name, module, sd0, lr, n_steps=2):
         upd = sd[k] - sd0[k].double()
         dn, ds = float(g[f"p_{name}_dnorms"][i]), float(g[f"p_{name}_dsums"][i])
         assert abs(float(upd.norm()) - dn) <= 1e-3 * dn, (k, float(upd.norm()), dn)
-        flip = 2 * lr * n_steps * (4 + 1e-4 * upd.numel())
+        # (2e-4 of the elements since round 3: the set of noise-level gradients whose sign differs from the reference's run is
+        # a property of the pair of fp32 implementations, not of either one -- changing only the order in which split-K partial
+        # tiles are summed moved iconv6.0.weight from 380 to 590 net flips of 4.7 M, with that layer's gradient as close to
+        # fp64 as the CPU reference's own: DESIGN.md, round 3, "gradient noise")
+        flip = 2 * lr * n_steps * (4 + 2e-4 * upd.numel())
         assert abs(float(upd.sum()) - ds) <= 1e-3 * dn + flip, (k, float(upd.sum()), ds)
 
 

@@ -10,12 +10,15 @@ from dvf.synthetic import synthetic_batch
 from dvf import lib as L
 B, H, W = int(os.environ.get("B", 4)), int(os.environ.get("H", 256)), int(os.environ.get("W", 832))
 if os.environ.get("SER"): L.SERIALIZE = True
-dsd = onets.fill_params(onets.dispnet_layers(), seed=1)
+from dvf import conv as _C
+if os.environ.get("FUSE") == "0": _C.FUSE_RELU_BWD = False
+if os.environ.get("DET") == "1": _C.set_deterministic(True)
+dsd = onets.fill_params(onets.dispnet_layers(), seed=int(os.environ.get("WSEED", 1)))
 psd = onets.fill_params(onets.posenet_layers(6, 6, 2, True), seed=2)
 disp, pose = DispNetS.DispNetS(), PoseExpNet.PoseExpNet(output_exp=True)
 disp.load_state_dict({k: v.clone() for k, v in dsd.items()}); pose.load_state_dict({k: v.clone() for k, v in psd.items()})
 disp.cuda().train(); pose.cuda().train()
-batch = synthetic_batch(B, H, W, seed=1234, device="cuda")
+batch = synthetic_batch(B, H, W, seed=int(os.environ.get("SEED", 1234)), device="cuda")
 # --- HIP, with the disparity output's gradient retained
 import loss_functions as LF
 from dvf.conv import reciprocal
@@ -35,7 +38,7 @@ hip_out = d0.detach().double().cpu()
 def oracle(dt):
     ds = {k: v.detach().clone().to(dt).requires_grad_(True) for k, v in dsd.items()}
     ps = {k: v.detach().clone().to(dt).requires_grad_(True) for k, v in psd.items()}
-    bt = osteps.synthetic_batch(B, H, W, seed=1234, dtype=dt)
+    bt = osteps.synthetic_batch(B, H, W, seed=int(os.environ.get("SEED", 1234)), dtype=dt)
     r2, r1, l2 = bt["img_R2"], bt["img_R1"], bt["img_L2"]
     o0 = onets.dispnet_forward(ds, r2)[0]; o0.retain_grad()
     _, t21 = onets.posenet_forward(ps, torch.cat((r2, r1), 1), 2, True, sfm=False); t21.retain_grad()
@@ -46,8 +49,13 @@ def oracle(dt):
     return ({"disp": {k: v.grad.double() for k, v in ds.items() if v.grad is not None},
              "pose": {k: v.grad.double() for k, v in ps.items() if v.grad is not None}}, o0.grad.double(), t21.grad.double(), o0.detach().double())
 
-r32, d32, t32, o32 = oracle(torch.float32)
-r64, d64, t64, o64 = oracle(torch.float64)
+cache = os.environ.get("ORACLE_CACHE")      # several HIP configurations against one oracle run (same B, H, W)
+if cache and os.path.exists(cache):
+    (r32, d32, t32, o32), (r64, d64, t64, o64) = torch.load(cache)
+else:
+    r32, d32, t32, o32 = oracle(torch.float32)
+    r64, d64, t64, o64 = oracle(torch.float64)
+    if cache: torch.save(((r32, d32, t32, o32), (r64, d64, t64, o64)), cache)
 def rel(a, b, den): return float((a - b).norm() / den.norm())
 print("disp out : hip-32 %.2e hip-64 %.2e 32-64 %.2e" % (rel(hip_out, o32, o32), rel(hip_out, o64, o32), rel(o32, o64, o32)))
 print("g_disp0  : hip-32 %.2e hip-64 %.2e 32-64 %.2e" % (rel(hip_d0, d32, d32), rel(hip_d0, d64, d32), rel(d32, d64, d32)))
@@ -55,3 +63,7 @@ print("g_T21    : hip-32 %.2e hip-64 %.2e 32-64 %.2e" % (rel(hip_T, t32, t32), r
 for n in ("disp", "pose"):
     for k in hip[n]:
         print("%-5s %-24s hip-32 %.2e hip-64 %.2e 32-64 %.2e" % (n, k, rel(hip[n][k], r32[n][k], r32[n][k]), rel(hip[n][k], r64[n][k], r32[n][k]), rel(r32[n][k], r64[n][k], r32[n][k])))
+
+if os.environ.get("SUMMARY"):
+    keys = ["iconv1.0", "upconv2.0", "iconv3.0", "upconv3.0", "predict_disp4.0", "iconv4.0", "upconv4.0", "iconv5.0", "iconv6.0", "iconv7.0", "conv7.0", "conv6.0", "conv5.0", "conv4.0", "conv3.0"]
+    print("SUMMARY " + os.environ["SUMMARY"] + ": " + "  ".join("%s %.2f" % (k, rel(hip["disp"][k + ".weight"], r64["disp"][k + ".weight"], r32["disp"][k + ".weight"]) / rel(r32["disp"][k + ".weight"], r64["disp"][k + ".weight"], r32["disp"][k + ".weight"])) for k in keys))

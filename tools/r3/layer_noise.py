@@ -17,7 +17,15 @@ LAYERS = [  # name, cin segs, cout, k, s, p, op, transposed, (N,H,W)
     ("upconv7 T 512->512 2x7", [512], 512, 3, 2, 1, 1, True, (4, 2, 7)),
     ("iconv7 1024->512 @4x13", [512, 512], 512, 3, 1, 1, 0, False, (4, 4, 13)),
     ("iconv5 512->256 @16x52", [256, 256], 256, 3, 1, 1, 0, False, (4, 16, 52)),
+    ("upconv3 T 128->64 32x104", [128], 64, 3, 2, 1, 1, True, (4, 32, 104)),
+    ("upconv4 T 256->128 16x52", [256], 128, 3, 2, 1, 1, True, (4, 16, 52)),
+    ("iconv4 256->128 @32x104", [128, 128], 128, 3, 1, 1, 0, False, (4, 32, 104)),
+    ("iconv3 129->64 @64x208", [64, 64, 1], 64, 3, 1, 1, 0, False, (4, 64, 208)),
+    ("predict4 128->1 @32x104", [128], 1, 3, 1, 1, 0, False, (4, 32, 104)),
+    ("predict3 64->1 @64x208", [64], 1, 3, 1, 1, 0, False, (4, 64, 208)),
 ]
+if len(sys.argv) > 1:
+    LAYERS = [l for l in LAYERS if any(a in l[0] for a in sys.argv[1:])]
 rms = lambda x: float(x.double().pow(2).mean().sqrt())
 for name, segs, cout, k, s, p, op, tr, (n, h, w) in LAYERS:
     g = torch.Generator().manual_seed(5)

@@ -27,6 +27,9 @@ LAYERS = [  # name, segs, cout, k, s, p, op, transposed, (N,H,W)
     ("upconv6 T3x3s2 512->512 @4x13", [512], 512, 3, 2, 1, 1, 1, (4, 4, 13)),
     ("pose conv6 3x3s2 256->256 @8x26", [256], 256, 3, 2, 1, 0, 0, (4, 8, 26)),
     ("pose conv7 3x3s2 256->256 @4x13", [256], 256, 3, 2, 1, 0, 0, (4, 4, 13)),
+    ("head 128->1 @32x104", [128], 1, 3, 1, 1, 0, 0, (4, 32, 104)),
+    ("head 128->2 @32x104", [128], 2, 3, 1, 1, 0, 0, (4, 32, 104)),
+    ("head 64->1 @64x208", [64], 1, 3, 1, 1, 0, 0, (4, 64, 208)),
 ]
 if len(sys.argv) > 1:
     LAYERS = [l for l in LAYERS if any(a in l[0] for a in sys.argv[1:])]
