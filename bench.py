@@ -172,7 +172,7 @@ def pmc_traffic(kernel):
         return None
 
 
-TRAFFIC_FILE = next((f for f in ("r02b_traffic.json", "r02_traffic.json", "r01_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r01_traffic.json")
+TRAFFIC_FILE = next((f for f in ("r03_traffic.json", "r02b_traffic.json", "r02_traffic.json", "r01_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r01_traffic.json")
 
 
 def measure_kernels(step):

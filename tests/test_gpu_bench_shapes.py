@@ -92,10 +92,13 @@ def test_fullsize_step_vs_oracle():
             r64 = grads64[name][k]
             floor, e64 = float((r - r64).norm()) / rn, float((g - r64).norm()) / rn
             assert e_norm < TOL or abs(float(g.norm()) - float(r64.norm())) / rn < max(TOL, 2 * abs(float(r.norm()) - float(r64.norm())) / rn), (name, k, e_norm)
-            # direction: 2e-4, or 8x the distance of the fp32 ORACLE ITSELF from the fp64 truth for this parameter
-            # (measured table: profiles/r02_fullstep_gradient_noise.txt -- the noise grows with depth, 1e-6 at full
-            # resolution to 2.5e-4 (oracle) / 1.4e-3 (HIP) at the 2x7 layers, whose gradients are sums with heavy
-            # cancellation; the MFMA kernels accumulate K sequentially where oneDNN sums in blocks, hence the factor)
+            # direction: 2e-4, or 8x the distance of the fp32 ORACLE ITSELF from the fp64 truth for this parameter.
+            # Round 3 measured what that factor is (profiles/r03_gradient_noise_seeds.txt, r03_noise_knobs.txt,
+            # r03_blocked_accumulation.txt): with the SAME kernels the ratio |g - g64| / |g32 - g64| of the deep layers is
+            # 0.3 ... 8 depending on the data / weight seed alone, and on this seed it moves 0.9 <-> 9 with the summation
+            # blocking of the forward / dgrad kernels although every layer's own rms error stays at or below torch's CPU
+            # kernels' (1.4-2.0e-7).  It counts which of two fp32 runs drew the worse set of ReLU-gate / bilinear-cell flips;
+            # it cannot be tightened to 2x by better arithmetic.  A wrong kernel is O(1) off.
             assert e_diff < max(2e-4, 8 * floor) and e64 < max(2e-4, 8 * floor), (name, k, e_diff, e64, floor)
     print("worst gradient: |g-ref|/|ref| = %.2e, norm error %.2e at %s" % worst)
 

@@ -18,6 +18,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 for c in 3 4 5; do python3 $R/bench.py --config $c --no-cpu-baseline > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err; done
 DVF_LAYER_TABLE=400 python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/layer_table.txt
+# per-layer kernel durations from the profiler (not from event brackets): call log of the recorded pass x kernel trace
+DVF_CALL_LOG=$O/calls.jsonl rocprofv3 --kernel-trace --output-format csv -d $O/prof_calls -o calls -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --serialize --no-cpu-baseline > /dev/null 2> $O/bench_calls.err
+python3 $R/tools/r3/launch_table.py $O/calls.jsonl $(ls $O/prof_calls/*kernel_trace.csv | head -1) > $O/launch_table.txt
+tail -12 $O/launch_table.txt
 find $O -name "*.csv" | head -30
 # keep the merged payload small: drop the per-launch traces, keep stats + counter csv
 find $O -name "*kernel_trace.csv" -size +8M -delete
