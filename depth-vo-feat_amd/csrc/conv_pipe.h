@@ -145,11 +145,11 @@ constexpr int PIPE_THREADS_4P = 512;
 constexpr int PIPE_MAXNPI = 32;    // patch pieces per channel (per-channel patch <= 2048 floats)
 
 // Blocked accumulation (PipeArgs::blk = n > 0): every n chunks the accumulators are added into a second register set and
-// cleared, so a long reduction (K = channels x taps of 1152 and more) is a sum of partial sums over ~150-300 terms like a
+// cleared (instantiations with BLK = 1), so a long reduction (K = channels x taps of 1152 and more) is a sum of partial sums over ~150-300 terms like a
 // blocked CPU GEMM's instead of one sequential fmaf chain (a 1161-term chain is 2.6x further from fp64 than torch's CPU
-// kernels, tools/r3/layer_noise.py; the full-step gradients were up to 5.8x further in round 2).  The second set costs no
-// occupancy: the kernel's register count is set by the producer waves' offset tables (141-155 VGPRs in every variant).
-template <int MT, int NT, int WM, int CKH, int TBU>
+// kernels, tools/r3/layer_noise.py).  The second set costs no occupancy (the kernel's register count is set by the
+// producer waves' offset tables, 141-155 VGPRs in every variant) but 1-2 % of a step when every instantiation carries it.
+template <int MT, int NT, int WM, int CKH, int TBU, int BLK = 0>
 __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeArgs a) {
     constexpr int CK = 2 * CKH, VW = CKH >= 4 ? 4 : CKH, CPG = CKH / VW, MTW = MT * WM;
     constexpr int UNITF = TBU * MTW * 64 * VW;             // packed floats per unit
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
         for (int j = 0; j < VW; ++j) bj[i][j] = bbase + j * 2 * PSR;
     }
     f32x16 acc[MT][NT];
-    f32x16 asum[MT][NT];                                   // (a.blk) running sum of the banked partial sums
+    f32x16 asum[BLK ? MT : 1][BLK ? NT : 1];              // (BLK) running sum of the banked partial sums
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[m][i][r] = 0.f;
-                asum[m][i][r] = 0.f;
+                if constexpr (BLK) asum[m][i][r] = 0.f;
             }
 
     // The chunk in stage `st`, unit by unit.  A unit is one kernel ROW (ta) x VW channel pairs: its TBU taps are
@@ -538,21 +538,23 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
                 if (a.IS == 2 && !a.x4) consume(st, std::integral_constant<int, 2>{});      // (de-interleaved rows)
                 else consume(st, std::integral_constant<int, 1>{});
             }
-            if (++since == a.blk) {     // (uniform; a.blk == 0: never)
-                since = 0;
+            if constexpr (BLK) {
+                if (++since == a.blk) {     // (uniform)
+                    since = 0;
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) {
-                        asum[m][i] += acc[m][i];
+                        for (int i = 0; i < NT; ++i) {
+                            asum[m][i] += acc[m][i];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
-                    }
+                            for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
+                        }
+                }
             }
             st = (st + 1 == a.NST) ? 0 : st + 1;
         }
     }
-    if (a.blk) {
+    if constexpr (BLK) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -693,17 +695,38 @@ template <int MT, int NT, int WM>
 int launch_pipe_family(const PipeArgs &a, int CKH, int TBU, dim3 grid, size_t lds, hipStream_t st, int threads);
 
 // blocks that use more than 64 KiB of LDS need the opt-in attribute (set once per kernel)
+// (BLK = 1, the instantiation with the second accumulator set, exists for the shapes the product banks: 64-channel waves,
+// 2- to 4-tap rows, 8- or 16-channel chunks; the tuning build has it for every shape -- DVF_PIPE_BLKT.  The other
+// instantiations keep round 2's register allocation: carrying the second set everywhere cost 1-2 % of a step.)
 template <int MT, int NT, int WM, int CKH, int TBU>
-inline int launch_pipe_one(const PipeArgs &a, dim3 grid, size_t lds, hipStream_t st, int threads) {
+constexpr bool pipe_has_blk() {
+#ifdef DVF_TUNING
+    return true;
+#else
+    return MT == 2 && NT == 1 && WM == 1 && CKH >= 4 && TBU >= 2 && TBU <= 4;
+#endif
+}
+
+template <int MT, int NT, int WM, int CKH, int TBU, int BLK>
+inline int launch_pipe_blk(const PipeArgs &a, dim3 grid, size_t lds, hipStream_t st, int threads) {
     static bool big_lds = false;
     if (lds > 64 * 1024 && !big_lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pipe_kernel<MT, NT, WM, CKH, TBU>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pipe_kernel<MT, NT, WM, CKH, TBU, BLK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return DVF_ERR_LAUNCH;
         big_lds = true;
     }
-    conv_pipe_kernel<MT, NT, WM, CKH, TBU><<<grid, threads, lds, st>>>(a);
+    conv_pipe_kernel<MT, NT, WM, CKH, TBU, BLK><<<grid, threads, lds, st>>>(a);
     return hipGetLastError() == hipSuccess ? DVF_OK : DVF_ERR_LAUNCH;
+}
+
+template <int MT, int NT, int WM, int CKH, int TBU>
+inline int launch_pipe_one(const PipeArgs &a, dim3 grid, size_t lds, hipStream_t st, int threads) {
+    if (a.blk) {
+        if constexpr (pipe_has_blk<MT, NT, WM, CKH, TBU>()) return launch_pipe_blk<MT, NT, WM, CKH, TBU, 1>(a, grid, lds, st, threads);
+        else return DVF_ERR_UNSUPPORTED;
+    }
+    return launch_pipe_blk<MT, NT, WM, CKH, TBU, 0>(a, grid, lds, st, threads);
 }
 
 template <int MT, int NT, int WM, int CKH>
