@@ -466,7 +466,7 @@ def main():
         result["roofline"] = {"kernel": "conv_pipe_kernel (Conv2d/ConvTranspose2d forward + dgrad; a call = the launch plus its "
                                         "split-K reduce where used)",
                               "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic("conv_fwd_dgrad") if quoted else None,
+                              "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic("conv_pipe") if quoted else None,
                               "traffic_source": ("profiles/%s: HBM-side bytes per launch from separate rocprofv3 --pmc passes of "
                                                  "this command (committed; not measured in this run)" % TRAFFIC_FILE) if quoted else None,
                               "calls_per_step": g_calls, "ms_per_step": g_ms,
