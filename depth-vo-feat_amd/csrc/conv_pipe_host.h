@@ -454,7 +454,8 @@ int plan_pipe(PipeArgs &a, const ClassSpec *cls, int ncls, PipePlan &pl, bool he
         const int64_t nblocks_total = (int64_t)pl.grid.x * pl.grid.y * pl.grid.z;
         static const bool no4p = dvf_tune("DVF_PIPE_NO4P") != nullptr;
         // (32-channel MFMA waves need <= 128 VGPRs: two 8-wave blocks still fit a CU)
-        pl.threads = (!no4p && (pl.lds > 76 * 1024 || nblocks_total <= 256 || MT == 1)) ? dvfp::PIPE_THREADS_4P : dvfp::PIPE_THREADS;
+        static const int mt1_4p = dvf_tune("DVF_PIPE_MT1_4P") ? atoi(dvf_tune("DVF_PIPE_MT1_4P")) : 1;      // tuning knob
+        pl.threads = (!no4p && (pl.lds > 76 * 1024 || nblocks_total <= 256 || (MT == 1 && mt1_4p))) ? dvfp::PIPE_THREADS_4P : dvfp::PIPE_THREADS;
     }
     return DVF_OK;
 }
