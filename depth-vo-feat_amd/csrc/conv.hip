@@ -943,6 +943,12 @@ int scatter_classes(int S, int pad, int KH, int KW, int OH, int OW, ClassSpec *c
             for (int i = 0; i < na; ++i)
                 for (int j = 0; j < nb; ++j) c.tapmap[i * nb + j] = ta[i] * KW + tb[j];
         }
+    // heaviest class first (longest-processing-time order: a launch dispatches its classes in this order, class-major, so the
+    // 4-tap blocks of a 3x3 stride-2 launch start first and the 1-tap blocks fill the tail -- conv_pipe.h, blockIdx.z)
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && cls[j].TA * cls[j].TB > cls[j - 1].TA * cls[j - 1].TB; --j) {
+            const ClassSpec t = cls[j]; cls[j] = cls[j - 1]; cls[j - 1] = t;
+        }
     return n;
 }
 

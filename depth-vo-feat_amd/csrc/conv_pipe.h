@@ -158,7 +158,8 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
     const int stage_floats = a.SLmax + CK * a.PSRmax;
     const int tid = threadIdx.x, lane = tid & 63, nl = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int zc = blockIdx.z % a.ncls, zr = blockIdx.z / a.ncls;
+    const int zper = gridDim.z / a.ncls;                   // class-major: every block of the heaviest class is dispatched first
+    const int zc = blockIdx.z / zper, zr = blockIdx.z - zc * zper;
     const int ng = zr / a.KS, ks = zr - ng * a.KS;
     const PClass c = a.cls[zc];
     const int tX = blockIdx.x % a.tilesX, tY = blockIdx.x / a.tilesX;
@@ -416,13 +417,15 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
     // (tools/micro/mfma_mix.hip), scalar and LDS instructions cost none, so address arithmetic is kept scalar except
     // for that one add per row.  The next unit's fragments are fetched behind the current unit's MFMAs
     // (unconditionally: past the end of the chunk they read LDS that nobody uses).
-    auto consume = [&](int st, auto isc) {
-        constexpr int IS = decltype(isc)::value;
+    // TBE = taps of this class's rows that are actually multiplied: TBU, or TBU-1 for the narrower parity classes of a strided
+    // launch (their packed rows are zero-padded to TBU taps: a 3x3 stride-2 launch would spend 12 tap slots on 9 taps)
+    auto consume = [&](int st, auto isc, auto tbec) {
+        constexpr int IS = decltype(isc)::value, TBE = decltype(tbec)::value;
         const float *wl = smem + st * stage_floats;
         const float *patch = wl + a.SLmax;
         const float *ap = wl + (wm * MT) * 64 * VW + lane * VW;
         avec af[2][MT];                                    // A fragments: ping-pong by tap (one tap ahead)
-        float bf[2][TBU][NT][VW];                          // B fragments: ping-pong by unit (one unit ahead)
+        float bf[2][TBE][NT][VW];                          // B fragments: ping-pong by unit (one unit ahead)
         int lta = 0, lcpg = 0, lk = 0;                     // load iterator (scalar): next unit to fetch
         // B rows of the next unit for channel pair j (all tiles): TBU consecutive floats of one patch row each
         auto load_bj = [&](auto bufc, auto jc) {
@@ -433,11 +436,11 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
                 const float *prow = prow0 + bj[i][j];
                 if constexpr (IS == 1) {
 #pragma unroll
-                    for (int u = 0; u < TBU; ++u) bf[buf][u][i][j] = prow[u];
+                    for (int u = 0; u < TBE; ++u) bf[buf][u][i][j] = prow[u];
                 } else {
                     const float *prow2 = prow + PWH;       // odd columns of the de-interleaved row
 #pragma unroll
-                    for (int u = 0; u < TBU; ++u) bf[buf][u][i][j] = (u & 1) ? prow2[u >> 1] : prow[u >> 1];
+                    for (int u = 0; u < TBE; ++u) bf[buf][u][i][j] = (u & 1) ? prow2[u >> 1] : prow[u >> 1];
                 }
             }
         };
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
             using TP = std::integral_constant<int, tp>;
             mma_j(bufc, TP{}, uc, std::integral_constant<int, 0>{});
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (u + 1 < TBU) load_a(std::integral_constant<int, tp ^ 1>{}, lk - 1, std::integral_constant<int, u + 1>{});
+            if constexpr (u + 1 < TBE) load_a(std::integral_constant<int, tp ^ 1>{}, lk - 1, std::integral_constant<int, u + 1>{});
             else load_a(std::integral_constant<int, tp ^ 1>{}, lk, std::integral_constant<int, 0>{});
             if constexpr (u == 0) load_bj(nbufc, std::integral_constant<int, 0>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -507,12 +510,12 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
         };
         auto unit = [&](auto bufc, auto nbufc, auto pbc) {
             step(bufc, nbufc, pbc, std::integral_constant<int, 0>{});
-            if constexpr (TBU > 1) step(bufc, nbufc, pbc, std::integral_constant<int, 1>{});
-            if constexpr (TBU > 2) step(bufc, nbufc, pbc, std::integral_constant<int, 2>{});
-            if constexpr (TBU > 3) step(bufc, nbufc, pbc, std::integral_constant<int, 3>{});
-            if constexpr (TBU > 4) step(bufc, nbufc, pbc, std::integral_constant<int, 4>{});
-            if constexpr (TBU > 5) step(bufc, nbufc, pbc, std::integral_constant<int, 5>{});
-            if constexpr (TBU > 6) step(bufc, nbufc, pbc, std::integral_constant<int, 6>{});
+            if constexpr (TBE > 1) step(bufc, nbufc, pbc, std::integral_constant<int, 1>{});
+            if constexpr (TBE > 2) step(bufc, nbufc, pbc, std::integral_constant<int, 2>{});
+            if constexpr (TBE > 3) step(bufc, nbufc, pbc, std::integral_constant<int, 3>{});
+            if constexpr (TBE > 4) step(bufc, nbufc, pbc, std::integral_constant<int, 4>{});
+            if constexpr (TBE > 5) step(bufc, nbufc, pbc, std::integral_constant<int, 5>{});
+            if constexpr (TBE > 6) step(bufc, nbufc, pbc, std::integral_constant<int, 6>{});
             advance();
         };
         load_b(B0{});
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
         __builtin_amdgcn_sched_barrier(0);
         for (int k = 0; k < NU; k += 2) {
             unit(B0{}, B1{}, std::integral_constant<int, 0>{});                 // taps 0 .. TBU-1: A parity starts at 0
-            if (k + 1 < NU) unit(B1{}, B0{}, std::integral_constant<int, TBU & 1>{});
+            if (k + 1 < NU) unit(B1{}, B0{}, std::integral_constant<int, TBE & 1>{});
         }
     };
 
@@ -535,8 +538,11 @@ __global__ __launch_bounds__(PIPE_THREADS_4P) void conv_pipe_kernel(const PipeAr
             DVF_STAMP(a, tb1);
             w_bar += tb1 - tb0;
             if (!DVF_DBG(a, 4)) {
-                if (a.IS == 2 && !a.x4) consume(st, std::integral_constant<int, 2>{});      // (de-interleaved rows)
-                else consume(st, std::integral_constant<int, 1>{});
+                using TBfull = std::integral_constant<int, TBU>;
+                using TBless = std::integral_constant<int, (TBU > 1 ? TBU - 1 : 1)>;
+                if (a.IS == 2 && !a.x4) consume(st, std::integral_constant<int, 2>{}, TBfull{});      // (de-interleaved rows)
+                else if (TBU > 1 && c.TB == TBU - 1 && !DVF_DBG(a, 64)) consume(st, std::integral_constant<int, 1>{}, TBless{});
+                else consume(st, std::integral_constant<int, 1>{}, TBfull{});
             }
             if constexpr (BLK) {
                 if (++since == a.blk) {     // (uniform)
