@@ -15,7 +15,9 @@ One process per GPU (RCCL = torch.distributed backend "nccl"); weak scaling: eve
 are sum-all-reduced over flat arena buckets during backward and averaged inside the fused Adam.  Started WITHOUT a
 launcher, `--gpus N` (N > 1) spawns the N rank processes itself before any GPU call.  Rank 0 prints ONE JSON line:
 `value` counts samples of all ranks over the slowest rank's time; `roofline*` objects come from HIP-event brackets around
-every kernel call of one serialised step measured live; `cpu_baseline` is the CPU oracle timed on this host."""
+every kernel call of one serialised step measured live (`roofline` = the calls whose plan ran conv_pipe_kernel, attributed
+through the library's plan log; `conv_calls_by_kernel` lists every kernel family); `host_enqueue_ms` is the host time to
+enqueue one step; `cpu_baseline` is the CPU oracle timed on this host."""
 import argparse
 import json
 import os
